@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the trace_ray hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the synthetic
+1,000,000-triangle soup (PCG32 seed 0x5EED0001), one 3840x2160 frame at four samples per pixel:
+camera rays generated on the device, nearest-hit search, one sun shadow ray per lit hit, shading,
+sub-sample average, RGBA8. One step = one frame. Mrays/s counts nearest-hit plus shadow searches.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 the same frame is split into 32x32-pixel tiles dealt out diagonally to the ranks
+(every rank holds the whole scene) and rank 0 collects the tiles with one RCCL gather per frame,
+overlapped with the next frame's rendering ("scaling": "strong").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK = 157.3e12   # vector FP32, FLOP/s
+HBM_PEAK = 8.0e12      # B/s
+FLOP_BOX, FLOP_TRI = 18, 46          # per slab test / per triangle test
+BYTES_BOX, BYTES_TRI = 32, 36        # structure bytes per slab test / per triangle test
+
+
+def cpu_baseline(objects, width, height, target_seconds=15.0):
+    """Times the CPU oracle (a C++ restatement of the reference's linear packet scan, AVX2/FMA)
+    on a strided pixel subsample of the same frame. Reported next to the GPU number; never part
+    of the measured path."""
+    from oracle import oracle_ffi as O
+
+    cores = O.default_threads()
+    sc = O.OracleScene(objects)
+    kw = dict(grid=2, reflect_depth=1, diffuse_depth=1)
+    stride = 8192
+    t0 = time.perf_counter()
+    _, _, rays = sc.render(width, height, pixel_stride=stride, n_threads=cores, **kw)
+    dt = time.perf_counter() - t0
+    rate = rays / dt
+    # Scale the sample so that the timed run takes about target_seconds.
+    want = max(rays, int(rate * target_seconds))
+    stride = max(1, int(stride * rays / want))
+    t0 = time.perf_counter()
+    _, _, rays = sc.render(width, height, pixel_stride=stride, n_threads=cores, **kw)
+    dt = time.perf_counter() - t0
+    sc.close()
+    return {
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"every {stride}th pixel of the {width}x{height} frame, 4 samples each: {rays} rays "
+                  f"(nearest-hit + shadow) in {dt:.1f} s; C++ restatement of the reference's AVX2 linear scan",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd import Context, Scene, render_params, scenes
+    from raytracing_amd import distributed as rd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 needs torch.distributed.run with N processes")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H = args.width, args.height
+    objects = scenes.soup(args.tris, args.seed)
+    ctx = Context(local_rank)
+    t0 = time.perf_counter()
+    scene = Scene(ctx, objects)
+    build_s = time.perf_counter() - t0
+
+    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0,
+                      shard_index=rank, shard_count=world)
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+
+    if world == 1:
+        frames = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)]
+        slab_bytes = 0
+    else:
+        slab = rd.slab_tiles(W, H, world)
+        slab_bytes = slab * rd.TILE_BYTES
+        frames = [torch.zeros(slab_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        full = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+        comm_stream = torch.cuda.Stream(device=dev)
+        render_done = [torch.cuda.Event() for _ in range(2)]
+        gather_done = [torch.cuda.Event() for _ in range(2)]
+
+    # Counters of one frame from the instrumented build (not timed).
+    st = scene.render_device_stats(p, frames[0].data_ptr())
+    counts = torch.tensor([st["rays"], st["box_tests"], st["tri_tests"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_total, box_total, tri_total = [int(x) for x in counts.tolist()]
+
+    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    k_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i, timed_index=None):
+        b = i % 2
+        if world == 1:
+            if timed_index is not None:
+                k_start[timed_index].record(stream)
+            scene.render_device(p, frames[0].data_ptr(), None, sh)
+            if timed_index is not None:
+                k_end[timed_index].record(stream)
+            return
+        # The buffer must not be overwritten before its previous gather has read it.
+        stream.wait_event(gather_done[b])
+        if timed_index is not None:
+            k_start[timed_index].record(stream)
+        scene.render_device(p, frames[b].data_ptr(), None, sh)
+        if timed_index is not None:
+            k_end[timed_index].record(stream)
+        render_done[b].record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(render_done[b])
+            gathered, _ = rd.gather_slabs(frames[b], slab_bytes, dst=0)
+            if rank == 0:
+                ctx.deinterleave_device(gathered.data_ptr(), slab, W, H, world, full.data_ptr(),
+                                        comm_stream.cuda_stream)
+                gathered.record_stream(comm_stream)
+            gather_done[b].record(comm_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(k_start, k_end)]))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_total * args.steps / elapsed / 1e6
+        # Roofline of the frame kernel on this rank (per launch): algorithmic bytes = frame bytes
+        # written + structure bytes of the slab and triangle tests the launch performs.
+        my_box, my_tri = st["box_tests"], st["tri_tests"]
+        frame_bytes = (W * H * 4) // world
+        alg_bytes = frame_bytes + BYTES_BOX * my_box + BYTES_TRI * my_tri
+        alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
+        achieved = alg_bytes / (kernel_ms * 1e-3)
+        out = {
+            "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays)",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"soup-{args.tris} seed {args.seed:#x}, {W}x{H}, 4 samples/pixel, primary + sun-shadow rays, "
+                            f"shade + resolve to RGBA8 on device",
+                "rays_per_frame": rays_total,
+                "box_tests_per_ray": box_total / max(1, rays_total),
+                "tri_tests_per_ray": tri_total / max(1, rays_total),
+                "scene_build_s": build_s,
+                "parallelism": f"tiles{world}" if world > 1 else "single",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_render",
+                "achieved": achieved / 1e9,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK,
+                "traffic": None,
+                "kernel_ms": kernel_ms,
+                "alg_bytes_per_launch": alg_bytes,
+                "valu_tflops": alg_flops / (kernel_ms * 1e-3) / 1e12,
+                "valu_frac": alg_flops / (kernel_ms * 1e-3) / FP32_PEAK,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(objects, W, H)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

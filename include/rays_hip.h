@@ -1,0 +1,164 @@
+/*
+ * rays_hip.h -- C ABI of the MI355X (gfx950) implementation of the reference ray tracer's
+ * trace_ray hot path: nearest-hit and any-hit search over packed triangles, plus the frame
+ * driver around it.
+ *
+ * The reference (a Rust crate) has no FFI; the boundary below replaces its Rust function API.
+ * Each entry point names the reference interface it stands in for (paths relative to the
+ * reference root). Per-ray calls become batch calls; the host keeps the Object / World fields
+ * and hands over flat arrays.
+ *
+ * Conventions
+ *  - Every function returns 0 on success and a negative rt_status otherwise; nothing throws or
+ *    aborts across the boundary. rt_last_error() returns a thread-local message for the last
+ *    failure on the calling thread.
+ *  - The caller owns every input and output buffer. rt_scene_build copies what it needs; the
+ *    library owns device memory until rt_scene_destroy / rt_ctx_destroy.
+ *  - A built scene is immutable. Calls on one rt_ctx are serialised internally.
+ *  - Hit id = (sum of the triangle counts of the preceding objects) + index of the triangle in
+ *    the object's post-optimize_model order. This is the index the reference uses into
+ *    Object.tri_data (src/main.rs:119,144,161). 0xFFFFFFFF means miss.
+ *  - Functions with the suffix _device take device pointers (memory of the context's GPU) and a
+ *    hipStream_t passed as void*; they enqueue work and return without synchronising.
+ */
+#ifndef RAYS_HIP_H
+#define RAYS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_MISS 0xFFFFFFFFu
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument (null pointer, zero size, index out of range ...) */
+    RT_ERR_DEVICE = -2,    /* a HIP call failed                                               */
+    RT_ERR_NOMEM = -3,     /* host or device allocation failed                                */
+    RT_ERR_UNSUPPORTED = -4
+} rt_status;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+/* One object, as Object::from receives it (src/objects.rs:25-31,42-61). */
+typedef struct {
+    const float*    verts;     /* n_verts * 3 floats, Object.verts                           */
+    uint32_t        n_verts;
+    const uint32_t* tris;      /* n_tris * 3 vertex indices, Object.tris BEFORE optimize_model */
+    uint32_t        n_tris;
+    const float*    tri_data;  /* n_tris * 6 floats: TriangleData.normal xyz, .color rgb     */
+    float           albedo_over_pi;  /* Material.albedo as Material::new stores it
+                                        (src/objects.rs:183-190: albedo / PI)                */
+    float           reflectivity;
+    float           roughness;
+} rt_object_desc;
+
+/* Ray (src/objects.rs:64-68). inv_dir is derived as 1.0f / d, as every caller in the reference
+ * does (dir.recip()). */
+typedef struct { float o[3], d[3]; } rt_ray;
+
+/* Result of one nearest-hit search. u and v are the barycentrics the reference computes and
+ * drops (src/simd_accel.rs:298,303). */
+typedef struct { uint32_t tri; float t, u, v; } rt_hit;
+
+/* Frame description: the constants of src/main.rs:29-36 made parameters. */
+typedef struct {
+    uint32_t width, height;   /* WIDTH, HEIGHT                                               */
+    uint32_t grid;            /* n: n x n sub-samples per pixel. 2 reproduces the reference's
+                                 four fixed samples in its order (src/main.rs:322-364)       */
+    uint32_t reflect_depth;   /* REFLECT_DEPTH (reference: 4)                                */
+    uint32_t diffuse_depth;   /* DIFFUSE_DEPTH (reference: 2)                                */
+    uint32_t diffuse_scatt;   /* DIFFUSE_SCATT (reference: 10)                               */
+    float    sun[3];          /* World.sun                                                   */
+    uint32_t seed;            /* key of the counter-based generator that replaces
+                                 rand::random (src/main.rs:262,264)                          */
+    uint32_t shard_index;     /* this GPU's rank among shard_count tile owners               */
+    uint32_t shard_count;     /* 1 = render the whole frame                                  */
+} rt_render_params;
+
+/* Counters of one rt_render*_stats call. */
+typedef struct {
+    uint64_t rays;        /* nearest-hit + any-hit searches                                  */
+    uint64_t box_tests;   /* ray / AABB slab tests                                           */
+    uint64_t tri_tests;   /* ray / triangle tests                                            */
+    uint64_t node_visits; /* inner-node fetches                                              */
+} rt_stats;
+
+#define RT_TILE 32u   /* screen tiles are RT_TILE x RT_TILE pixels                           */
+
+/* ---- context --------------------------------------------------------------------------- */
+/* Binds the library to GPU devices[0] (n must be 1: one process per GPU). Fails with
+ * RT_ERR_DEVICE when no gfx950 device is available. No reference counterpart: the reference
+ * runs on the host only. */
+int  rt_ctx_create(const int* devices, int n, rt_ctx** out);
+void rt_ctx_destroy(rt_ctx*);
+
+/* ---- scene ----------------------------------------------------------------------------- */
+/* Replaces optimize_model + pack_model (src/opt.rs:11-80, src/main.rs:450-454): sorts every
+ * object's triangles with the reference's key, precomputes e1 = b - a, e2 = c - a, v0 = a per
+ * triangle as pack_triangles does (src/simd_accel.rs:8-66), builds the traversal structure and
+ * uploads it. */
+int  rt_scene_build(rt_ctx*, const rt_object_desc* objs, uint32_t n_objs, rt_scene** out);
+void rt_scene_destroy(rt_scene*);
+/* Total triangle count (the hit-id space). */
+uint32_t rt_scene_num_tris(const rt_scene*);
+/* optimize_model's permutation for one object: order[i] = input position of the triangle at
+ * sorted position i (src/opt.rs:12-35). */
+int  rt_scene_order(const rt_scene*, uint32_t obj, uint32_t* order);
+/* The packed arrays pack_model produces (src/opt.rs:38-80), read back from device memory:
+ * tris9 = n_tris * 9 floats (e1 xyz, e2 xyz, v0 xyz) in sorted order, leaf_bounds = n_tris/8
+ * boxes of 6 floats (min xyz, max xyz). Either pointer may be null. */
+int  rt_scene_packed(const rt_scene*, uint32_t obj, float* tris9, float* leaf_bounds6);
+
+/* ---- search ---------------------------------------------------------------------------- */
+/* Replaces the nearest-hit search of trace_ray (src/main.rs:93-171) for n rays. Host buffers. */
+int  rt_trace_closest(rt_scene*, const rt_ray* rays, uint64_t n, rt_hit* out);
+/* Replaces the shadow search of trace_ray (src/main.rs:185-233): occluded[i] = 1 when the ray
+ * hits anything. Host buffers. */
+int  rt_trace_any(rt_scene*, const rt_ray* rays, uint64_t n, uint8_t* occluded);
+/* Same two searches on device buffers. */
+int  rt_trace_closest_device(rt_scene*, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
+                             void* stream);
+int  rt_trace_any_device(rt_scene*, const rt_ray* d_rays, uint64_t n, uint8_t* d_occluded,
+                         void* stream);
+/* The reference's own search order run on the GPU: every 8-triangle leaf box of every object
+ * in turn, no tree (src/main.rs:100-171). Slow; exists so that arithmetic parity can be checked
+ * apart from tree traversal. Host buffers. */
+int  rt_trace_closest_linear(rt_scene*, const rt_ray* rays, uint64_t n, rt_hit* out);
+
+/* ---- frame ----------------------------------------------------------------------------- */
+/* Replaces draw (src/main.rs:313-379) including the trace_ray recursion under it
+ * (src/main.rs:88-311): camera rays, nearest-hit search, sun shadow search, shading, mirror and
+ * diffuse bounces, gamma, sub-sample average, RGBA8. rgba8 = width * height * 4 bytes (host).
+ * hit_ids (nullable) = width * height * grid * grid primary hit ids, [pixel][sample]. With
+ * shard_count > 1 only this shard's tiles are written; the rest of the buffers is untouched. */
+int  rt_render(rt_scene*, const rt_render_params*, uint8_t* rgba8, uint32_t* hit_ids);
+/* Device-buffer form. With shard_count > 1, d_rgba8 is this shard's compact tile buffer of
+ * rt_shard_tiles() tiles, each RT_TILE * RT_TILE * 4 bytes, in ascending tile id. */
+int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
+                      void* stream);
+/* As rt_render_device, from an instrumented build of the same kernels; synchronises and fills
+ * *stats. Used for the roofline figures, never for timing. */
+int  rt_render_device_stats(rt_scene*, const rt_render_params*, uint8_t* d_rgba8,
+                            uint32_t* d_hit_ids, rt_stats* stats);
+/* Number of tiles shard_index owns out of shard_count for a width x height frame. */
+uint32_t rt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_index,
+                        uint32_t shard_count);
+/* Scatters gathered compact tile buffers back into a width * height * 4 frame. d_gathered holds
+ * shard_count slabs of slab_tiles tiles each (slab s = the output of shard s). No reference
+ * counterpart: the reference renders on one host. */
+int  rt_deinterleave_tiles_device(rt_ctx*, const uint8_t* d_gathered, uint32_t slab_tiles,
+                                  uint32_t width, uint32_t height, uint32_t shard_count,
+                                  uint8_t* d_rgba8, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------ */
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+"""ctypes binding of the CPU oracle (oracle/librays_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by the cpu_baseline
+leg of bench.py, always as the checker or the timed baseline, never by the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "librays_oracle.so")
+
+MISS = 0xFFFFFFFF
+
+
+class rto_object_desc(C.Structure):
+    _fields_ = [
+        ("verts", C.POINTER(C.c_float)),
+        ("n_verts", C.c_uint32),
+        ("tris", C.POINTER(C.c_uint32)),
+        ("n_tris", C.c_uint32),
+        ("tri_data", C.POINTER(C.c_float)),
+        ("albedo_over_pi", C.c_float),
+        ("reflectivity", C.c_float),
+        ("roughness", C.c_float),
+    ]
+
+
+class rto_render_params(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("grid", C.c_uint32),
+        ("reflect_depth", C.c_uint32),
+        ("diffuse_depth", C.c_uint32),
+        ("diffuse_scatt", C.c_uint32),
+        ("sun", C.c_float * 3),
+        ("seed", C.c_uint32),
+        ("pixel_stride", C.c_uint32),
+    ]
+
+
+RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3)])
+HIT_DTYPE = np.dtype([("tri", np.uint32), ("t", np.float32), ("u", np.float32), ("v", np.float32),
+                      ("closest", np.float32)])
+
+_VP = C.c_void_p
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        L.rto_scene_create.restype = _VP
+        L.rto_scene_create.argtypes = [C.POINTER(rto_object_desc), C.c_uint32]
+        L.rto_scene_destroy.argtypes = [_VP]
+        L.rto_scene_num_tris.restype = C.c_uint32
+        L.rto_scene_num_tris.argtypes = [_VP]
+        L.rto_scene_order.argtypes = [_VP, C.c_uint32, _VP]
+        for name in ("rto_scene_num_packed_tris", "rto_scene_num_packed_bounds", "rto_scene_num_rest_bounds",
+                     "rto_scene_num_rest_tri"):
+            getattr(L, name).restype = C.c_uint32
+            getattr(L, name).argtypes = [_VP, C.c_uint32]
+        for name in ("rto_scene_packed_tris", "rto_scene_packed_bounds", "rto_scene_rest_bounds",
+                     "rto_scene_object_bounds"):
+            getattr(L, name).argtypes = [_VP, C.c_uint32, _VP]
+        L.rto_trace_closest.argtypes = [_VP, _VP, C.c_uint64, _VP, C.c_int]
+        L.rto_trace_any.argtypes = [_VP, _VP, C.c_uint64, _VP, C.c_int]
+        L.rto_render.argtypes = [_VP, C.POINTER(rto_render_params), _VP, _VP, C.POINTER(C.c_uint64), C.c_int]
+        L.rto_packed_boxes_intersect.argtypes = [_VP, _VP, C.c_float, _VP]
+        L.rto_packed_tris_intersect.argtypes = [_VP, _VP, C.c_float, _VP, _VP, _VP]
+        L.rto_box_intersection_check.argtypes = [_VP, _VP, _VP, _VP]
+        L.rto_triangle_ray_hits.argtypes = [_VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]
+        L.rto_calculate_normal.argtypes = [_VP, _VP, _VP, _VP]
+        L.rto_calculate_normal.restype = None
+        L.rto_rand.restype = C.c_float
+        L.rto_rand.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_VP) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def default_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def as_rays(rays):
+    r = np.ascontiguousarray(rays)
+    if r.dtype != RAY_DTYPE:
+        r = np.ascontiguousarray(np.asarray(rays, dtype=np.float32).reshape(-1, 6)).view(RAY_DTYPE).reshape(-1)
+    return r
+
+
+class OracleScene:
+    def __init__(self, objects):
+        from raytracing_amd._ffi import make_descs
+
+        self.L = lib()
+        descs, keep = make_descs(objects, rto_object_desc)
+        self.n_objs = len(objects)
+        self.obj_tris = [len(np.asarray(o["tris"]).reshape(-1, 3)) for o in objects]
+        self.handle = self.L.rto_scene_create(descs, len(objects))
+        del keep
+
+    def close(self):
+        if self.handle:
+            self.L.rto_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_tris(self):
+        return self.L.rto_scene_num_tris(self.handle)
+
+    def order(self, obj):
+        out = np.empty(self.obj_tris[obj], dtype=np.uint32)
+        self.L.rto_scene_order(self.handle, obj, _p(out))
+        return out
+
+    def packed_tris(self, obj):
+        """(n_packets, 9, 8): e1.x[8] e1.y e1.z e2.x e2.y e2.z v0.x v0.y v0.z."""
+        n = self.L.rto_scene_num_packed_tris(self.handle, obj)
+        out = np.empty((n, 9, 8), dtype=np.float32)
+        self.L.rto_scene_packed_tris(self.handle, obj, _p(out))
+        return out
+
+    def packed_bounds(self, obj):
+        """(n_packets, 6, 8): min.x[8] min.y min.z max.x max.y max.z."""
+        n = self.L.rto_scene_num_packed_bounds(self.handle, obj)
+        out = np.empty((n, 6, 8), dtype=np.float32)
+        self.L.rto_scene_packed_bounds(self.handle, obj, _p(out))
+        return out
+
+    def rest_bounds(self, obj):
+        n = self.L.rto_scene_num_rest_bounds(self.handle, obj)
+        out = np.empty((n, 6), dtype=np.float32)
+        self.L.rto_scene_rest_bounds(self.handle, obj, _p(out))
+        return out
+
+    def num_rest_tri(self, obj):
+        return self.L.rto_scene_num_rest_tri(self.handle, obj)
+
+    def object_bounds(self, obj):
+        out = np.empty(6, dtype=np.float32)
+        self.L.rto_scene_object_bounds(self.handle, obj, _p(out))
+        return out
+
+    def trace_closest(self, rays, n_threads=None):
+        r = as_rays(rays)
+        out = np.empty(len(r), dtype=HIT_DTYPE)
+        self.L.rto_trace_closest(self.handle, _p(r), len(r), _p(out), n_threads or default_threads())
+        return out
+
+    def trace_any(self, rays, n_threads=None):
+        r = as_rays(rays)
+        out = np.empty(len(r), dtype=np.uint8)
+        self.L.rto_trace_any(self.handle, _p(r), len(r), _p(out), n_threads or default_threads())
+        return out
+
+    def render(self, width, height, grid=2, reflect_depth=4, diffuse_depth=2, diffuse_scatt=10,
+               sun=(0.0, 25000.0, 100000.0), seed=0, pixel_stride=1, want_hit_ids=False, n_threads=None):
+        p = rto_render_params()
+        p.width, p.height, p.grid = width, height, grid
+        p.reflect_depth, p.diffuse_depth, p.diffuse_scatt = reflect_depth, diffuse_depth, diffuse_scatt
+        p.sun[0], p.sun[1], p.sun[2] = [float(x) for x in sun]
+        p.seed, p.pixel_stride = seed, pixel_stride
+        rgba = np.zeros((height, width, 4), dtype=np.uint8)
+        ids = np.full(width * height * grid * grid, MISS, dtype=np.uint32) if want_hit_ids else None
+        count = C.c_uint64(0)
+        rc = self.L.rto_render(self.handle, C.byref(p), _p(rgba), _p(ids), C.byref(count),
+                               n_threads or default_threads())
+        assert rc == 0
+        return rgba, ids, count.value
+
+
+def packed_boxes_intersect(boxes48, ray6, ray_length):
+    L = lib()
+    b = _f32(boxes48).reshape(48)
+    r = _f32(ray6).reshape(6)
+    out = np.empty(8, dtype=np.float32)
+    mask = L.rto_packed_boxes_intersect(_p(b), _p(r), float(ray_length), _p(out))
+    return out, mask
+
+
+def packed_tris_intersect(tris72, ray6, ray_length):
+    L = lib()
+    t = _f32(tris72).reshape(72)
+    r = _f32(ray6).reshape(6)
+    to, uo, vo = (np.empty(8, dtype=np.float32) for _ in range(3))
+    mask = L.rto_packed_tris_intersect(_p(t), _p(r), float(ray_length), _p(to), _p(uo), _p(vo))
+    return to, uo, vo, mask
+
+
+def box_intersection_check(origin, inv_dir, bmin, bmax):
+    L = lib()
+    o, i, mn, mx = _f32(origin), _f32(inv_dir), _f32(bmin), _f32(bmax)
+    return bool(L.rto_box_intersection_check(_p(o), _p(i), _p(mn), _p(mx)))
+
+
+def triangle_ray_hits(a, b, c, ray6, min_dist):
+    L = lib()
+    a, b, c, r = _f32(a), _f32(b), _f32(c), _f32(ray6).reshape(6)
+    t, u, v = (np.zeros(1, dtype=np.float32) for _ in range(3))
+    hit = L.rto_triangle_ray_hits(_p(a), _p(b), _p(c), _p(r), float(min_dist), _p(t), _p(u), _p(v))
+    return (float(t[0]), float(u[0]), float(v[0])) if hit else None
+
+
+def calculate_normal(a, b, c):
+    L = lib()
+    a, b, c = _f32(a), _f32(b), _f32(c)
+    out = np.empty(3, dtype=np.float32)
+    L.rto_calculate_normal(_p(a), _p(b), _p(c), _p(out))
+    return out
+
+
+def rand(seed, sample_index, scatter, which):
+    return float(lib().rto_rand(seed, sample_index, scatter, which))

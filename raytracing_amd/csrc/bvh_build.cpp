@@ -1,0 +1,332 @@
+// bvh_build.cpp -- binned-SAH binary build over single triangles, then a collapse to 4-wide
+// nodes laid out in depth-first order. Host code; runs once per scene.
+
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace rtbvh {
+namespace {
+
+constexpr int BINS = 16;
+constexpr float PAD_REL = 6e-6f;  // relative widening of every triangle box, per axis
+
+struct Prim {
+    float lo[3], hi[3], c[3];
+};
+
+struct Node2 {
+    float lo[3], hi[3];
+    uint32_t left = 0, right = 0;   // inner: child node indices
+    uint32_t first = 0, count = 0;  // leaf when count > 0: range in idx[]
+};
+
+struct Box3 {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    float hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* l, const float* h) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], l[k]);
+            hi[k] = std::max(hi[k], h[k]);
+        }
+    }
+    void grow_pt(const float* p) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0.0f) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+class Builder {
+   public:
+    Builder(std::vector<Prim>& prims, int n_threads, bool balanced)
+        : prims_(prims), idx_(prims.size()), nodes_(2 * prims.size() + 1), next_(0), balanced_(balanced) {
+        for (size_t i = 0; i < idx_.size(); ++i) idx_[i] = (uint32_t)i;
+        int d = 0;
+        while ((1 << d) < std::max(1, n_threads) * 2) ++d;
+        par_depth_ = n_threads > 1 ? d : 0;
+    }
+
+    uint32_t run() { return rec(0, (uint32_t)prims_.size(), par_depth_); }
+
+    std::vector<Prim>& prims_;
+    std::vector<uint32_t> idx_;
+    std::vector<Node2> nodes_;
+
+   private:
+    std::atomic<uint32_t> next_;
+    int par_depth_;
+    bool balanced_;  // median splits only: bounds the depth at ceil(log2 n)
+
+    uint32_t rec(uint32_t begin, uint32_t end, int par) {
+        const uint32_t me = next_.fetch_add(1);
+        Node2& node = nodes_[me];
+        const uint32_t n = end - begin;
+        Box3 bb, cb;
+        for (uint32_t i = begin; i < end; ++i) {
+            const Prim& p = prims_[idx_[i]];
+            bb.grow(p.lo, p.hi);
+            cb.grow_pt(p.c);
+        }
+        std::memcpy(node.lo, bb.lo, sizeof(bb.lo));
+        std::memcpy(node.hi, bb.hi, sizeof(bb.hi));
+        if (n == 1) {
+            node.first = begin;
+            node.count = 1;
+            return me;
+        }
+
+        if (balanced_) {
+            if (n <= MAX_LEAF) {
+                node.first = begin;
+                node.count = n;
+                return me;
+            }
+            int k = 0;
+            for (int a = 1; a < 3; ++a)
+                if (cb.hi[a] - cb.lo[a] > cb.hi[k] - cb.lo[k]) k = a;
+            const uint32_t mid = begin + n / 2;
+            std::nth_element(idx_.begin() + begin, idx_.begin() + mid, idx_.begin() + end,
+                             [&](uint32_t a, uint32_t b) { return prims_[a].c[k] < prims_[b].c[k]; });
+            uint32_t l, r;
+            if (par > 0 && n > 16384) {
+                std::thread th([&]() { l = rec(begin, mid, par - 1); });
+                r = rec(mid, end, par - 1);
+                th.join();
+            } else {
+                l = rec(begin, mid, 0);
+                r = rec(mid, end, 0);
+            }
+            node.left = l;
+            node.right = r;
+            node.count = 0;
+            return me;
+        }
+
+        // Binned SAH over the three axes.
+        float best_cost = FLT_MAX;
+        int best_axis = -1, best_split = -1;
+        float scale[3];
+        for (int k = 0; k < 3; ++k) {
+            float ext = cb.hi[k] - cb.lo[k];
+            scale[k] = ext > 0.0f ? (float)BINS * (1.0f - 1e-6f) / ext : 0.0f;
+        }
+        if (scale[0] > 0.0f || scale[1] > 0.0f || scale[2] > 0.0f) {
+            Box3 bins[3][BINS];
+            uint32_t cnt[3][BINS];
+            std::memset(cnt, 0, sizeof(cnt));
+            for (uint32_t i = begin; i < end; ++i) {
+                const Prim& p = prims_[idx_[i]];
+                for (int k = 0; k < 3; ++k) {
+                    int b = (int)((p.c[k] - cb.lo[k]) * scale[k]);
+                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                    bins[k][b].grow(p.lo, p.hi);
+                    cnt[k][b]++;
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                if (scale[k] <= 0.0f) continue;
+                float right_area[BINS];
+                uint32_t right_cnt[BINS];
+                Box3 acc;
+                uint32_t c = 0;
+                for (int b = BINS - 1; b > 0; --b) {
+                    if (cnt[k][b]) acc.grow(bins[k][b].lo, bins[k][b].hi);
+                    c += cnt[k][b];
+                    right_area[b] = acc.half_area();
+                    right_cnt[b] = c;
+                }
+                Box3 lacc;
+                uint32_t lc = 0;
+                for (int b = 0; b < BINS - 1; ++b) {
+                    if (cnt[k][b]) lacc.grow(bins[k][b].lo, bins[k][b].hi);
+                    lc += cnt[k][b];
+                    if (lc == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = lacc.half_area() * (float)lc + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = k;
+                        best_split = b + 1;  // bins < best_split go left
+                    }
+                }
+            }
+        }
+
+        const float area = bb.half_area();
+        if (n <= MAX_LEAF) {
+            // Leaf unless the split is clearly cheaper (traversal step priced at one triangle test).
+            const float leaf_cost = (float)n;
+            const float split_cost = (best_axis >= 0 && area > 0.0f) ? 1.0f + best_cost / area : FLT_MAX;
+            if (!(split_cost < leaf_cost)) {
+                node.first = begin;
+                node.count = n;
+                return me;
+            }
+        }
+
+        uint32_t mid;
+        if (best_axis >= 0) {
+            const int k = best_axis;
+            const float lo = cb.lo[k], sc = scale[k];
+            const int split = best_split;
+            uint32_t* first = idx_.data() + begin;
+            uint32_t* last = idx_.data() + end;
+            uint32_t* m = std::partition(first, last, [&](uint32_t id) {
+                int b = (int)((prims_[id].c[k] - lo) * sc);
+                b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                return b < split;
+            });
+            mid = (uint32_t)(m - idx_.data());
+        } else {
+            mid = begin;  // all centroids coincide
+        }
+        if (mid == begin || mid == end) mid = begin + n / 2;
+
+        uint32_t l, r;
+        if (par > 0 && n > 16384) {
+            std::thread th([&]() { l = rec(begin, mid, par - 1); });
+            r = rec(mid, end, par - 1);
+            th.join();
+        } else {
+            l = rec(begin, mid, 0);
+            r = rec(mid, end, 0);
+        }
+        node.left = l;
+        node.right = r;
+        node.count = 0;
+        return me;
+    }
+};
+
+struct Collapser {
+    const Builder& b;
+    Result& out;
+    uint32_t node_base, record_base;
+
+    uint32_t emit_leaf(const Node2& n) {
+        const uint32_t first = (uint32_t)out.order.size();
+        for (uint32_t i = 0; i < n.count; ++i) out.order.push_back(b.idx_[n.first + i]);
+        return LEAF_BIT | ((record_base + first) << 3) | (n.count - 1);
+    }
+
+    static float half_area(const Node2& n) {
+        float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    // Emits the 4-wide node for binary node `root2` (an inner node) and returns the pending-entry
+    // bound of its subtree.
+    uint32_t emit_inner(uint32_t root2, uint32_t* my_index) {
+        const uint32_t me = (uint32_t)out.nodes.size();
+        *my_index = me;
+        out.nodes.emplace_back();
+        uint32_t kids[4];
+        int nk = 0;
+        kids[nk++] = b.nodes_[root2].left;
+        kids[nk++] = b.nodes_[root2].right;
+        // Open the largest inner child until four slots are used.
+        while (nk < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int i = 0; i < nk; ++i) {
+                const Node2& c = b.nodes_[kids[i]];
+                if (c.count == 0) {
+                    float a = half_area(c);
+                    if (a > best) {
+                        best = a;
+                        pick = i;
+                    }
+                }
+            }
+            if (pick < 0) break;
+            const Node2& c = b.nodes_[kids[pick]];
+            kids[pick] = c.left;
+            kids[nk++] = c.right;
+        }
+        uint32_t deepest = 0;
+        Node4 n4;
+        std::memset(&n4, 0, sizeof(n4));
+        for (int i = 0; i < 4; ++i) {
+            if (i < nk) {
+                const Node2& c = b.nodes_[kids[i]];
+                n4.lox[i] = c.lo[0]; n4.loy[i] = c.lo[1]; n4.loz[i] = c.lo[2];
+                n4.hix[i] = c.hi[0]; n4.hiy[i] = c.hi[1]; n4.hiz[i] = c.hi[2];
+                if (c.count > 0) {
+                    n4.child[i] = emit_leaf(c);
+                } else {
+                    uint32_t ci;
+                    uint32_t d = emit_inner(kids[i], &ci);
+                    n4.child[i] = node_base + ci;
+                    deepest = std::max(deepest, d);
+                }
+            } else {
+                // An inverted box: every slab test on it fails for finite rays; the kernels also
+                // check the reference itself.
+                n4.lox[i] = n4.loy[i] = n4.loz[i] = INFINITY;
+                n4.hix[i] = n4.hiy[i] = n4.hiz[i] = -INFINITY;
+                n4.child[i] = EMPTY;
+            }
+        }
+        out.nodes[me] = n4;
+        return (uint32_t)(nk - 1) + deepest;
+    }
+};
+
+}  // namespace
+
+void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32_t record_base,
+           int n_threads, bool balanced, Result* out) {
+    out->nodes.clear();
+    out->order.clear();
+    out->max_stack = 0;
+    if (n == 0) return;
+    std::vector<Prim> prims(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* b = tri_bounds + 6 * (size_t)i;
+        Prim& p = prims[i];
+        for (int k = 0; k < 3; ++k) {
+            float lo = b[k], hi = b[3 + k];
+            float pad = std::max(std::fabs(lo), std::fabs(hi)) * PAD_REL + 1e-30f;
+            p.lo[k] = lo - pad;
+            p.hi[k] = hi + pad;
+            p.c[k] = 0.5f * lo + 0.5f * hi;
+        }
+    }
+    Builder b(prims, n_threads, balanced);
+    const uint32_t root = b.run();
+    out->nodes.reserve(n / 2 + 8);
+    out->order.reserve(n);
+    Collapser c{b, *out, node_index_base, record_base};
+    const Node2& r = b.nodes_[root];
+    if (r.count > 0) {
+        // A single leaf: wrap it in a one-child inner node so that the root is always inner.
+        Node4 n4;
+        std::memset(&n4, 0, sizeof(n4));
+        for (int i = 0; i < 4; ++i) {
+            n4.lox[i] = n4.loy[i] = n4.loz[i] = INFINITY;
+            n4.hix[i] = n4.hiy[i] = n4.hiz[i] = -INFINITY;
+            n4.child[i] = EMPTY;
+        }
+        n4.lox[0] = r.lo[0]; n4.loy[0] = r.lo[1]; n4.loz[0] = r.lo[2];
+        n4.hix[0] = r.hi[0]; n4.hiy[0] = r.hi[1]; n4.hiz[0] = r.hi[2];
+        out->nodes.push_back(n4);
+        out->nodes[0].child[0] = c.emit_leaf(r);
+        out->max_stack = 1;
+    } else {
+        uint32_t ri;
+        out->max_stack = c.emit_inner(root, &ri) + 1;
+    }
+}
+
+}  // namespace rtbvh

@@ -1,0 +1,597 @@
+// rt_api.cpp -- the C ABI of include/rays_hip.h: context, scene build, search and frame calls.
+// Host code; every piece of arithmetic that reaches a result runs in the kernels.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/rays_hip.h"
+#include "bvh_build.h"
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                \
+    } while (0)
+
+// Owns a set of device allocations; frees them unless released.
+struct DevPool {
+    std::vector<void*> ptrs;
+    ~DevPool() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    hipError_t alloc(void** out, size_t bytes) {
+        *out = nullptr;
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(out, bytes);
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+    void release() { ptrs.clear(); }
+};
+
+struct TileMap {
+    uint32_t tiles_x = 0, tiles_y = 0;
+    std::vector<uint32_t> list;  // tiles of one shard, ascending
+    uint32_t* d_list = nullptr;
+    std::vector<uint32_t> slot;  // every tile's rank within its shard
+    uint32_t* d_slot = nullptr;
+};
+
+inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+int host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    return (int)std::min(16u, n);
+}
+
+// f32::min / f32::max as glam's Vec3::min / max use them (the non-NaN operand wins).
+inline float g_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+inline float g_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, TileMap> tile_maps;
+    ~rt_ctx() {
+        for (auto& kv : tile_maps) {
+            if (kv.second.d_list) (void)hipFree(kv.second.d_list);
+            if (kv.second.d_slot) (void)hipFree(kv.second.d_slot);
+        }
+    }
+};
+
+struct rt_scene {
+    rt_ctx* ctx = nullptr;
+    SceneView view{};
+    std::vector<void*> device_ptrs;
+    uint32_t n_tris = 0;
+    uint32_t n_leaves = 0;
+    uint32_t n_nodes = 0;
+    uint32_t max_stack = 0;
+    std::vector<DevObject> objects;
+    std::vector<std::vector<uint32_t>> order;  // per object: sorted position -> input position
+    ~rt_scene() {
+        for (void* p : device_ptrs) (void)hipFree(p);
+    }
+};
+
+namespace {
+
+// Tiles of a width x height frame owned by shard `index` of `count`: tile (tx, ty) belongs to
+// shard (tx + ty) % count, so neighbouring tiles go to different GPUs in both directions.
+int get_tile_map(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t index, uint32_t count, TileMap** out) {
+    auto key = std::make_tuple(width, height, index, count);
+    auto it = ctx->tile_maps.find(key);
+    if (it != ctx->tile_maps.end()) {
+        *out = &it->second;
+        return RT_OK;
+    }
+    TileMap tm;
+    tm.tiles_x = ceil_div(width, RT_TILE);
+    tm.tiles_y = ceil_div(height, RT_TILE);
+    const uint32_t n = tm.tiles_x * tm.tiles_y;
+    tm.slot.resize(n);
+    std::vector<uint32_t> next(count, 0);
+    for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t shard = (t % tm.tiles_x + t / tm.tiles_x) % count;
+        tm.slot[t] = next[shard]++;
+        if (shard == index) tm.list.push_back(t);
+    }
+    HIP_TRY(hipMalloc((void**)&tm.d_list, std::max<size_t>(16, tm.list.size() * 4)));
+    HIP_TRY(hipMalloc((void**)&tm.d_slot, std::max<size_t>(16, tm.slot.size() * 4)));
+    if (!tm.list.empty()) HIP_TRY(hipMemcpy(tm.d_list, tm.list.data(), tm.list.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(tm.d_slot, tm.slot.data(), tm.slot.size() * 4, hipMemcpyHostToDevice));
+    auto ins = ctx->tile_maps.emplace(key, std::move(tm));
+    *out = &ins.first->second;
+    return RT_OK;
+}
+
+int check_render_params(const rt_render_params* p, uint32_t* spp) {
+    if (!p) return fail(RT_ERR_INVALID, "render params are null");
+    if (p->width == 0 || p->height == 0) return fail(RT_ERR_INVALID, "frame size is zero");
+    if ((uint64_t)p->width * p->height > (1ull << 30)) return fail(RT_ERR_INVALID, "frame too large");
+    if (p->grid != 1 && p->grid != 2 && p->grid != 4 && p->grid != 8)
+        return fail(RT_ERR_UNSUPPORTED, "grid must be 1, 2, 4 or 8 (got %u)", p->grid);
+    if (p->reflect_depth > RT_MAX_REFLECT + 1)
+        return fail(RT_ERR_UNSUPPORTED, "reflect_depth above %d is not supported", RT_MAX_REFLECT + 1);
+    if (p->diffuse_depth > 2) return fail(RT_ERR_UNSUPPORTED, "diffuse_depth above 2 is not supported");
+    if (p->diffuse_depth > 1 && p->diffuse_scatt == 0) return fail(RT_ERR_INVALID, "diffuse_scatt is zero");
+    if (p->shard_count == 0 || p->shard_index >= p->shard_count)
+        return fail(RT_ERR_INVALID, "shard_index %u out of range for shard_count %u", p->shard_index, p->shard_count);
+    *spp = p->grid * p->grid;
+    return RT_OK;
+}
+
+int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
+                  hipStream_t stream) {
+    uint32_t spp = 0;
+    int rc = check_render_params(p, &spp);
+    if (rc != RT_OK) return rc;
+    if (!d_rgba8) return fail(RT_ERR_INVALID, "rgba8 buffer is null");
+    DevRenderParams dp{};
+    dp.width = p->width;
+    dp.height = p->height;
+    dp.grid = p->grid;
+    dp.spp = spp;
+    dp.reflect_depth = p->reflect_depth;
+    dp.diffuse_depth = p->diffuse_depth;
+    dp.diffuse_scatt = p->diffuse_scatt;
+    dp.sun[0] = p->sun[0];
+    dp.sun[1] = p->sun[1];
+    dp.sun[2] = p->sun[2];
+    dp.seed = p->seed;
+    dp.tiles_x = ceil_div(p->width, RT_TILE);
+    const uint32_t* d_list = nullptr;
+    if (p->shard_count > 1) {
+        TileMap* tm = nullptr;
+        rc = get_tile_map(s->ctx, p->width, p->height, p->shard_index, p->shard_count, &tm);
+        if (rc != RT_OK) return rc;
+        dp.n_tiles = (uint32_t)tm->list.size();
+        dp.compact = 1;
+        d_list = tm->d_list;
+    } else {
+        dp.n_tiles = dp.tiles_x * ceil_div(p->height, RT_TILE);
+        dp.compact = 0;
+    }
+    const bool bounces = p->diffuse_depth > 1;
+    HIP_TRY(rtk::render(s->view, dp, d_list, bounces, d_rgba8, d_hit_ids, d_stats, stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+const char* rt_version(void) { return "rays-hip 0.1 (gfx950)"; }
+
+int rt_ctx_create(const int* devices, int n, rt_ctx** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!devices || n != 1) return fail(RT_ERR_INVALID, "exactly one device per context (one process per GPU)");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (devices[0] < 0 || devices[0] >= count)
+        return fail(RT_ERR_DEVICE, "device %d not present (%d visible)", devices[0], count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, devices[0]));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", devices[0],
+                    prop.gcnArchName);
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(RT_ERR_NOMEM, "out of host memory");
+    c->device = devices[0];
+    *out = c;
+    return RT_OK;
+}
+
+void rt_ctx_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    delete c;
+}
+
+int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!ctx || !objs || n_objs == 0) return fail(RT_ERR_INVALID, "ctx / objs null or no objects");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // ---- validate, and lay all objects out in shared arrays --------------------------------
+    uint64_t total_tris = 0, total_verts = 0;
+    for (uint32_t o = 0; o < n_objs; ++o) {
+        const rt_object_desc& d = objs[o];
+        if (!d.verts || d.n_verts == 0) return fail(RT_ERR_INVALID, "object %u has no vertices", o);
+        if (d.n_tris > 0 && (!d.tris || !d.tri_data)) return fail(RT_ERR_INVALID, "object %u: tris / tri_data null", o);
+        for (uint64_t i = 0; i < (uint64_t)d.n_tris * 3; ++i)
+            if (d.tris[i] >= d.n_verts)
+                return fail(RT_ERR_INVALID, "object %u: vertex index %u out of range (%u vertices)", o, d.tris[i],
+                            d.n_verts);
+        total_tris += d.n_tris;
+        total_verts += d.n_verts;
+    }
+    if (total_tris >= (1ull << 27)) return fail(RT_ERR_UNSUPPORTED, "more than 2^27 triangles");
+    if (total_verts >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "more than 2^32 vertices");
+
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
+    struct Guard {
+        rt_scene* s;
+        ~Guard() { delete s; }
+    } guard{s};
+    s->ctx = ctx;
+    s->n_tris = (uint32_t)total_tris;
+    s->objects.resize(n_objs);
+    s->order.resize(n_objs);
+
+    std::vector<float> verts_all((size_t)total_verts * 3);
+    std::vector<uint32_t> tris_all((size_t)total_tris * 3);  // sorted, vertex indices offset per object
+    std::vector<float> data_all((size_t)total_tris * 6);     // sorted
+    std::vector<uint32_t> leaf_first;                        // global sorted index of each leaf's first triangle
+    std::vector<float> rest_verts;
+    std::vector<float> bounds;                               // per packed triangle, for the tree build
+
+    uint32_t tri_base = 0, vert_base = 0;
+    for (uint32_t o = 0; o < n_objs; ++o) {
+        const rt_object_desc& d = objs[o];
+        DevObject& ob = s->objects[o];
+        std::memcpy(&verts_all[(size_t)vert_base * 3], d.verts, (size_t)d.n_verts * 12);
+        // Object::from, src/objects.rs:48-53.
+        float mn[3] = {d.verts[0], d.verts[1], d.verts[2]}, mx[3] = {d.verts[0], d.verts[1], d.verts[2]};
+        for (uint32_t i = 0; i < d.n_verts; ++i)
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = g_min(mn[k], d.verts[3 * (size_t)i + k]);
+                mx[k] = g_max(mx[k], d.verts[3 * (size_t)i + k]);
+            }
+        std::memcpy(ob.bbmin, mn, 12);
+        std::memcpy(ob.bbmax, mx, 12);
+        // optimize_model, src/opt.rs:11-36: stable sort, smallest vertex index ascending, then
+        // largest vertex index descending.
+        std::vector<uint32_t>& ord = s->order[o];
+        ord.resize(d.n_tris);
+        for (uint32_t i = 0; i < d.n_tris; ++i) ord[i] = i;
+        const uint32_t* T = d.tris;
+        std::stable_sort(ord.begin(), ord.end(), [T](uint32_t a, uint32_t b) {
+            const uint32_t *ta = T + 3 * (size_t)a, *tb = T + 3 * (size_t)b;
+            const uint32_t amin = std::min(std::min(ta[0], ta[1]), ta[2]);
+            const uint32_t bmin = std::min(std::min(tb[0], tb[1]), tb[2]);
+            if (amin != bmin) return amin < bmin;
+            const uint32_t amax = std::max(std::max(ta[0], ta[1]), ta[2]);
+            const uint32_t bmax = std::max(std::max(tb[0], tb[1]), tb[2]);
+            return amax > bmax;
+        });
+        for (uint32_t i = 0; i < d.n_tris; ++i) {
+            const uint32_t src = ord[i];
+            for (int k = 0; k < 3; ++k) tris_all[3 * (size_t)(tri_base + i) + k] = T[3 * (size_t)src + k] + vert_base;
+            std::memcpy(&data_all[6 * (size_t)(tri_base + i)], d.tri_data + 6 * (size_t)src, 24);
+        }
+        ob.tri_base = tri_base;
+        ob.n_tris = d.n_tris;
+        ob.n_packed = (d.n_tris / 8) * 8;
+        ob.n_rest = d.n_tris - ob.n_packed;
+        ob.rest_base = (uint32_t)(rest_verts.size() / 9);
+        ob.leaf_base = (uint32_t)leaf_first.size();
+        ob.albedo = d.albedo_over_pi;
+        ob.reflectivity = d.reflectivity;
+        ob.roughness = d.roughness;
+        ob.root = rtbvh::EMPTY;
+        for (uint32_t l = 0; l < ob.n_packed / 8; ++l) leaf_first.push_back(tri_base + l * 8);
+        for (uint32_t i = ob.n_packed; i < d.n_tris; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const float* v = &verts_all[3 * (size_t)tris_all[3 * (size_t)(tri_base + i) + k]];
+                rest_verts.insert(rest_verts.end(), v, v + 3);
+            }
+        tri_base += d.n_tris;
+        vert_base += d.n_verts;
+    }
+    s->n_leaves = (uint32_t)leaf_first.size();
+
+    // ---- trees: one per object, over its 8-wide triangles ----------------------------------
+    std::vector<rtbvh::Node4> nodes_all;
+    std::vector<uint32_t> order_all;  // record -> global triangle id
+    const int nt = host_threads();
+    for (uint32_t o = 0; o < n_objs; ++o) {
+        DevObject& ob = s->objects[o];
+        if (ob.n_packed == 0) continue;
+        bounds.resize((size_t)ob.n_packed * 6);
+        for (uint32_t i = 0; i < ob.n_packed; ++i) {
+            const uint32_t* t = &tris_all[3 * (size_t)(ob.tri_base + i)];
+            const float *a = &verts_all[3 * (size_t)t[0]], *b = &verts_all[3 * (size_t)t[1]],
+                        *c = &verts_all[3 * (size_t)t[2]];
+            for (int k = 0; k < 3; ++k) {
+                bounds[6 * (size_t)i + k] = std::min(std::min(a[k], b[k]), c[k]);
+                bounds[6 * (size_t)i + 3 + k] = std::max(std::max(a[k], b[k]), c[k]);
+            }
+        }
+        rtbvh::Result res;
+        const uint32_t node_base = (uint32_t)nodes_all.size(), rec_base = (uint32_t)order_all.size();
+        rtbvh::build(bounds.data(), ob.n_packed, node_base, rec_base, nt, false, &res);
+        if (res.max_stack > RT_STACK_MAX) rtbvh::build(bounds.data(), ob.n_packed, node_base, rec_base, nt, true, &res);
+        if (res.max_stack > RT_STACK_MAX)
+            return fail(RT_ERR_UNSUPPORTED, "object %u: tree needs %u pending entries, limit %d", o, res.max_stack,
+                        RT_STACK_MAX);
+        s->max_stack = std::max(s->max_stack, res.max_stack);
+        ob.root = node_base;
+        nodes_all.insert(nodes_all.end(), res.nodes.begin(), res.nodes.end());
+        for (uint32_t r : res.order) order_all.push_back(ob.tri_base + r);
+    }
+    s->n_nodes = (uint32_t)nodes_all.size();
+
+    // ---- upload and pack on the device -----------------------------------------------------
+    DevPool pool;
+    float *d_verts, *d_tri9, *d_leaf_bounds, *d_data, *d_rest;
+    uint32_t *d_tris, *d_leaf_first, *d_order;
+    float4* d_recs;
+    rtbvh::Node4* d_nodes;
+    DevObject* d_objs;
+    DevPool tmp;  // freed on return
+    HIP_TRY(tmp.alloc((void**)&d_verts, verts_all.size() * 4));
+    HIP_TRY(tmp.alloc((void**)&d_tris, tris_all.size() * 4));
+    HIP_TRY(tmp.alloc((void**)&d_leaf_first, leaf_first.size() * 4));
+    HIP_TRY(tmp.alloc((void**)&d_order, order_all.size() * 4));
+    HIP_TRY(pool.alloc((void**)&d_tri9, (size_t)total_tris * 36));
+    HIP_TRY(pool.alloc((void**)&d_leaf_bounds, leaf_first.size() * 24));
+    HIP_TRY(pool.alloc((void**)&d_data, data_all.size() * 4));
+    HIP_TRY(pool.alloc((void**)&d_rest, rest_verts.size() * 4));
+    HIP_TRY(pool.alloc((void**)&d_recs, order_all.size() * 48));
+    HIP_TRY(pool.alloc((void**)&d_nodes, nodes_all.size() * sizeof(rtbvh::Node4)));
+    HIP_TRY(pool.alloc((void**)&d_objs, s->objects.size() * sizeof(DevObject)));
+    HIP_TRY(hipMemcpy(d_verts, verts_all.data(), verts_all.size() * 4, hipMemcpyHostToDevice));
+    if (!tris_all.empty()) HIP_TRY(hipMemcpy(d_tris, tris_all.data(), tris_all.size() * 4, hipMemcpyHostToDevice));
+    if (!leaf_first.empty())
+        HIP_TRY(hipMemcpy(d_leaf_first, leaf_first.data(), leaf_first.size() * 4, hipMemcpyHostToDevice));
+    if (!order_all.empty())
+        HIP_TRY(hipMemcpy(d_order, order_all.data(), order_all.size() * 4, hipMemcpyHostToDevice));
+    if (!data_all.empty()) HIP_TRY(hipMemcpy(d_data, data_all.data(), data_all.size() * 4, hipMemcpyHostToDevice));
+    if (!rest_verts.empty())
+        HIP_TRY(hipMemcpy(d_rest, rest_verts.data(), rest_verts.size() * 4, hipMemcpyHostToDevice));
+    if (!nodes_all.empty())
+        HIP_TRY(hipMemcpy(d_nodes, nodes_all.data(), nodes_all.size() * sizeof(rtbvh::Node4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_objs, s->objects.data(), s->objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+    HIP_TRY(rtk::pack_tris(d_verts, d_tris, (uint32_t)total_tris, d_tri9, 0));
+    HIP_TRY(rtk::leaf_bounds(d_verts, d_tris, d_leaf_first, (uint32_t)leaf_first.size(), d_leaf_bounds, 0));
+    HIP_TRY(rtk::gather_records(d_tri9, d_order, (uint32_t)order_all.size(), d_recs, 0));
+    HIP_TRY(hipDeviceSynchronize());
+
+    s->view.objs = d_objs;
+    s->view.n_objs = n_objs;
+    s->view.nodes = d_nodes;
+    s->view.recs = d_recs;
+    s->view.tri9 = d_tri9;
+    s->view.leaf_bounds = d_leaf_bounds;
+    s->view.tri_data = d_data;
+    s->view.rest_verts = d_rest;
+    s->device_ptrs = pool.ptrs;
+    pool.release();
+    guard.s = nullptr;
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    delete s;
+}
+
+uint32_t rt_scene_num_tris(const rt_scene* s) { return s ? s->n_tris : 0; }
+
+int rt_scene_order(const rt_scene* s, uint32_t obj, uint32_t* order) {
+    if (!s || !order) return fail(RT_ERR_INVALID, "null argument");
+    if (obj >= s->order.size()) return fail(RT_ERR_INVALID, "object %u out of range", obj);
+    if (!s->order[obj].empty()) std::memcpy(order, s->order[obj].data(), s->order[obj].size() * 4);
+    return RT_OK;
+}
+
+int rt_scene_packed(const rt_scene* s, uint32_t obj, float* tris9, float* leaf_bounds6) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (obj >= s->objects.size()) return fail(RT_ERR_INVALID, "object %u out of range", obj);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    const DevObject& ob = s->objects[obj];
+    if (tris9 && ob.n_tris)
+        HIP_TRY(hipMemcpy(tris9, s->view.tri9 + 9 * (size_t)ob.tri_base, (size_t)ob.n_tris * 36, hipMemcpyDeviceToHost));
+    if (leaf_bounds6 && ob.n_packed)
+        HIP_TRY(hipMemcpy(leaf_bounds6, s->view.leaf_bounds + 6 * (size_t)ob.leaf_base, (size_t)(ob.n_packed / 8) * 24,
+                          hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, void* stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (n == 0) return RT_OK;
+    if (!d_rays || !d_out) return fail(RT_ERR_INVALID, "null buffer");
+    if (n > (1ull << 31) * RT_BLOCK) return fail(RT_ERR_INVALID, "too many rays in one call");
+    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_trace_any_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, uint8_t* d_occluded, void* stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (n == 0) return RT_OK;
+    if (!d_rays || !d_occluded) return fail(RT_ERR_INVALID, "null buffer");
+    if (n > (1ull << 31) * RT_BLOCK) return fail(RT_ERR_INVALID, "too many rays in one call");
+    HIP_TRY(rtk::trace_any(s->view, d_rays, n, d_occluded, (hipStream_t)stream));
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+template <class OutT, class Launch>
+int trace_host(rt_scene* s, const rt_ray* rays, uint64_t n, OutT* out, Launch launch) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (n == 0) return RT_OK;
+    if (!rays || !out) return fail(RT_ERR_INVALID, "null buffer");
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    DevPool tmp;
+    rt_ray* d_rays;
+    OutT* d_out;
+    HIP_TRY(tmp.alloc((void**)&d_rays, n * sizeof(rt_ray)));
+    HIP_TRY(tmp.alloc((void**)&d_out, n * sizeof(OutT)));
+    HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    HIP_TRY(launch(d_rays, d_out));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_out, n * sizeof(OutT), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* out) {
+    return trace_host<rt_hit>(s, rays, n, out, [&](const rt_ray* dr, rt_hit* dout) {
+        return rtk::trace_closest(s->view, dr, n, dout, 0);
+    });
+}
+
+int rt_trace_any(rt_scene* s, const rt_ray* rays, uint64_t n, uint8_t* occluded) {
+    return trace_host<uint8_t>(s, rays, n, occluded, [&](const rt_ray* dr, uint8_t* dout) {
+        return rtk::trace_any(s->view, dr, n, dout, 0);
+    });
+}
+
+int rt_trace_closest_linear(rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* out) {
+    return trace_host<rt_hit>(s, rays, n, out, [&](const rt_ray* dr, rt_hit* dout) {
+        return rtk::trace_closest_linear(s->view, dr, n, dout, 0);
+    });
+}
+
+uint32_t rt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_index, uint32_t shard_count) {
+    if (shard_count == 0 || shard_index >= shard_count) return 0;
+    const uint32_t tx = ceil_div(width, RT_TILE), ty = ceil_div(height, RT_TILE);
+    uint32_t n = 0;
+    for (uint32_t y = 0; y < ty; ++y)
+        for (uint32_t x = 0; x < tx; ++x)
+            if ((x + y) % shard_count == shard_index) ++n;
+    return n;
+}
+
+int rt_render_device(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, void* stream) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    return render_common(s, p, d_rgba8, d_hit_ids, nullptr, (hipStream_t)stream);
+}
+
+int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids,
+                           rt_stats* stats) {
+    if (!s || !stats) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    DevPool tmp;
+    DevStats* d_stats;
+    HIP_TRY(tmp.alloc((void**)&d_stats, sizeof(DevStats)));
+    HIP_TRY(hipMemset(d_stats, 0, sizeof(DevStats)));
+    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    DevStats h;
+    HIP_TRY(hipMemcpy(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    stats->rays = h.rays;
+    stats->box_tests = h.box_tests;
+    stats->tri_tests = h.tri_tests;
+    stats->node_visits = h.node_visits;
+    return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_render_params* p, uint8_t* rgba8, uint32_t* hit_ids) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    uint32_t spp = 0;
+    int rc = check_render_params(p, &spp);
+    if (rc != RT_OK) return rc;
+    if (!rgba8) return fail(RT_ERR_INVALID, "rgba8 buffer is null");
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    const size_t n_pix = (size_t)p->width * p->height;
+    const bool sharded = p->shard_count > 1;
+    const uint32_t my_tiles = sharded ? rt_shard_tiles(p->width, p->height, p->shard_index, p->shard_count) : 0;
+    const size_t frame_bytes = sharded ? (size_t)my_tiles * RT_TILE * RT_TILE * 4 : n_pix * 4;
+    DevPool tmp;
+    uint8_t* d_rgba;
+    uint32_t* d_ids = nullptr;
+    HIP_TRY(tmp.alloc((void**)&d_rgba, frame_bytes));
+    HIP_TRY(hipMemset(d_rgba, 0, std::max<size_t>(frame_bytes, 16)));
+    if (hit_ids) {
+        HIP_TRY(tmp.alloc((void**)&d_ids, n_pix * spp * 4));
+        HIP_TRY(hipMemcpy(d_ids, hit_ids, n_pix * spp * 4, hipMemcpyHostToDevice));
+    }
+    rc = render_common(s, p, d_rgba, d_ids, nullptr, 0);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!sharded) {
+        HIP_TRY(hipMemcpy(rgba8, d_rgba, frame_bytes, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint8_t> compact(frame_bytes);
+        if (frame_bytes) HIP_TRY(hipMemcpy(compact.data(), d_rgba, frame_bytes, hipMemcpyDeviceToHost));
+        TileMap* tm = nullptr;
+        rc = get_tile_map(s->ctx, p->width, p->height, p->shard_index, p->shard_count, &tm);
+        if (rc != RT_OK) return rc;
+        for (size_t k = 0; k < tm->list.size(); ++k) {
+            const uint32_t t = tm->list[k], tx = t % tm->tiles_x, ty = t / tm->tiles_x;
+            for (uint32_t ly = 0; ly < RT_TILE; ++ly) {
+                const uint32_t y = ty * RT_TILE + ly;
+                if (y >= p->height) break;
+                const uint32_t x0 = tx * RT_TILE;
+                const uint32_t w = std::min<uint32_t>(RT_TILE, p->width - x0);
+                std::memcpy(rgba8 + ((size_t)y * p->width + x0) * 4,
+                            compact.data() + (k * RT_TILE * RT_TILE + (size_t)ly * RT_TILE) * 4, (size_t)w * 4);
+            }
+        }
+    }
+    if (hit_ids) HIP_TRY(hipMemcpy(hit_ids, d_ids, n_pix * spp * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_deinterleave_tiles_device(rt_ctx* ctx, const uint8_t* d_gathered, uint32_t slab_tiles, uint32_t width,
+                                 uint32_t height, uint32_t shard_count, uint8_t* d_rgba8, void* stream) {
+    if (!ctx || !d_gathered || !d_rgba8) return fail(RT_ERR_INVALID, "null argument");
+    if (width == 0 || height == 0 || shard_count == 0) return fail(RT_ERR_INVALID, "bad frame or shard count");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    TileMap* tm = nullptr;
+    int rc = get_tile_map(ctx, width, height, 0, shard_count, &tm);
+    if (rc != RT_OK) return rc;
+    for (uint32_t sh = 0; sh < shard_count; ++sh)
+        if (rt_shard_tiles(width, height, sh, shard_count) > slab_tiles)
+            return fail(RT_ERR_INVALID, "slab_tiles %u is smaller than shard %u's tile count", slab_tiles, sh);
+    HIP_TRY(rtk::deinterleave(d_gathered, tm->d_slot, slab_tiles, width, height, tm->tiles_x,
+                              tm->tiles_x * tm->tiles_y, shard_count, d_rgba8, (hipStream_t)stream));
+    return RT_OK;
+}
+
+}  // extern "C"

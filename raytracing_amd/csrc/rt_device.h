@@ -1,0 +1,60 @@
+// rt_device.h -- device-side data layout shared by the kernels and the host API.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bvh_build.h"
+
+#define RT_BLOCK 256        // threads per workgroup: four 64-lane waves
+#define RT_STACK_LDS 16     // traversal stack entries kept in LDS per lane
+#define RT_STACK_SPILL 80   // further entries in private memory
+#define RT_STACK_MAX (RT_STACK_LDS + RT_STACK_SPILL)
+#define RT_MAX_REFLECT 8    // deepest mirror chain the frame kernel keeps on its stack
+
+// One object of the World (src/objects.rs:18-39), as the kernels see it. 64 bytes.
+struct DevObject {
+    float bbmin[3];        // Object.bounding_box (src/objects.rs:48-58), exact
+    float bbmax[3];
+    uint32_t tri_base;     // global id of the object's first triangle
+    uint32_t n_tris;       // all triangles
+    uint32_t n_packed;     // 8 * (n_tris / 8): triangles tested with the 8-wide arithmetic
+    uint32_t root;         // index of the object's root node, EMPTY when n_packed == 0
+    uint32_t rest_base;    // first entry in rest_verts of the trailing n_tris % 8 triangles
+    uint32_t n_rest;
+    float albedo;          // Material (src/objects.rs:176-190); albedo already divided by PI
+    float reflectivity;
+    float roughness;
+    uint32_t leaf_base;    // first entry in leaf_bounds of the object's 8-triangle leaves
+};
+static_assert(sizeof(DevObject) == 64, "DevObject layout");
+
+// Everything a search needs, passed to kernels by value.
+struct SceneView {
+    const DevObject* objs;
+    uint32_t n_objs;
+    const rtbvh::Node4* nodes;  // all objects' trees, 128 B per node
+    const float4* recs;         // triangle records in tree-leaf order, 3 x float4 each:
+                                //   (v0.x v0.y v0.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z id - -)
+    const float* tri9;          // reference order: e1 xyz, e2 xyz, v0 xyz per triangle
+    const float* leaf_bounds;   // reference order: min xyz, max xyz per 8-triangle leaf
+    const float* tri_data;      // reference order: normal xyz, color rgb per triangle
+    const float* rest_verts;    // a xyz, b xyz, c xyz of every trailing triangle
+};
+
+struct DevRenderParams {
+    uint32_t width, height, grid, spp;
+    uint32_t reflect_depth, diffuse_depth, diffuse_scatt;
+    float sun[3];
+    uint32_t seed;
+    uint32_t tiles_x;          // tiles per row of the frame
+    uint32_t n_tiles;          // tiles this launch renders
+    uint32_t compact;          // 1: write tile-compact output, 0: write the frame in place
+};
+
+struct DevStats {
+    unsigned long long rays, box_tests, tri_tests, node_visits;
+};
+
+#endif

@@ -1,0 +1,732 @@
+// rt_kernels.hip -- gfx950 kernels for the trace_ray path: one ray per lane, wave64.
+//
+// Parity-critical arithmetic lives in rt_exact.h and is used unchanged here. The tree walk
+// itself only has to be conservative (it decides which triangles get tested, never the result
+// of a test), so its box test is free to use fused arithmetic.
+//
+// Compile with -ffp-contract=off (see rt_exact.h).
+
+#include "rt_kernels.h"
+
+#include "rt_exact.h"
+
+using rtbvh::EMPTY;
+using rtbvh::LEAF_BIT;
+using rtbvh::Node4;
+
+namespace {
+
+struct LaneStats {
+    uint32_t box = 0, tri = 0, node = 0, rays = 0;
+};
+
+struct HitD {
+    uint32_t tri;
+    uint32_t obj;
+    float t, u, v;
+    float closest;
+};
+
+__device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane traversal stack: RT_STACK_LDS entries in LDS (lane-interleaved, conflict-free
+// 8-byte accesses), the rest in private memory. An entry is (node reference, entry distance).
+// ---------------------------------------------------------------------------------------------
+struct LaneStack {
+    uint2* lds;    // &s_stack[threadIdx.x]; entry e lives at lds[e * RT_BLOCK]
+    uint2 spill[RT_STACK_SPILL];
+    int sp;
+    __device__ __forceinline__ void push(uint32_t node, float tnear) {
+        uint2 e = make_uint2(node, __float_as_uint(tnear));
+        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = e;
+        else if (sp < RT_STACK_MAX) spill[sp - RT_STACK_LDS] = e;
+        // The host refuses trees whose pending-entry bound exceeds RT_STACK_MAX, so the
+        // stack cannot overflow; the guard above only keeps a corrupt tree from writing wild.
+        sp = sp < RT_STACK_MAX ? sp + 1 : sp;
+    }
+    __device__ __forceinline__ uint2 pop() {
+        --sp;
+        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[sp - RT_STACK_LDS];
+    }
+};
+
+#define RT_CSWAP(ka, kb, ca, cb)            \
+    {                                       \
+        bool sw_ = (ka) > (kb);             \
+        float tk_ = sw_ ? (kb) : (ka);      \
+        float tl_ = sw_ ? (ka) : (kb);      \
+        uint32_t tc_ = sw_ ? (cb) : (ca);   \
+        uint32_t td_ = sw_ ? (ca) : (cb);   \
+        (ka) = tk_; (kb) = tl_; (ca) = tc_; (cb) = td_; \
+    }
+
+// Walks one object's tree. Nearest-hit mode (ANY == false) keeps the reference's acceptance rule
+// for 8-wide triangles (src/main.rs:117, src/simd_accel.rs:307-322): not failed, t > 0,
+// closest > t; ties on t go to the lower triangle id because the reference scans ids upward
+// with a strict compare. `local_best` starts at 0 so that a tie with the incoming `closest`
+// (a hit in an earlier object) is rejected, as the strict compare does.
+// Shadow mode (ANY == true) returns at the first triangle whose lane of the reference's result
+// has a clear sign bit (src/main.rs:199-204). A NaN t is treated as a miss: x86 produces
+// NaNs with the sign bit set, gfx950 with it clear.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, uint32_t obj_index, rt_f3 o,
+                                           rt_f3 d, rt_f3 inv, float& closest, HitD& hit, LaneStack& stk,
+                                           LaneStats& st) {
+    const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
+    uint32_t local_best = 0;
+    stk.sp = 0;
+    uint32_t cur = root;
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
+            const float4 lox = np[0], loy = np[1], loz = np[2];
+            const float4 hix = np[3], hiy = np[4], hiz = np[5];
+            const uint4 ch = *reinterpret_cast<const uint4*>(np + 6);
+            if (STATS) {
+                st.node += 1;
+                st.box += 4;
+            }
+            float k0, k1, k2, k3;
+            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define RT_BOX(K, C, LX, LY, LZ, HX, HY, HZ)                                                        \
+    {                                                                                                \
+        float ax = __builtin_fmaf(LX, inv.x, nox), bx = __builtin_fmaf(HX, inv.x, nox);              \
+        float ay = __builtin_fmaf(LY, inv.y, noy), by = __builtin_fmaf(HY, inv.y, noy);              \
+        float az = __builtin_fmaf(LZ, inv.z, noz), bz = __builtin_fmaf(HZ, inv.z, noz);              \
+        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));           \
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));        \
+        K = ((C) != EMPTY && tn <= tf) ? tn : RT_INF;                                                \
+    }
+            RT_BOX(k0, c0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x)
+            RT_BOX(k1, c1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y)
+            RT_BOX(k2, c2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z)
+            RT_BOX(k3, c3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w)
+#undef RT_BOX
+            RT_CSWAP(k0, k1, c0, c1)
+            RT_CSWAP(k2, k3, c2, c3)
+            RT_CSWAP(k0, k2, c0, c2)
+            RT_CSWAP(k1, k3, c1, c3)
+            RT_CSWAP(k1, k2, c1, c2)
+            if (k3 < RT_INF) stk.push(c3, k3);
+            if (k2 < RT_INF) stk.push(c2, k2);
+            if (k1 < RT_INF) stk.push(c1, k1);
+            if (k0 < RT_INF) {
+                cur = c0;
+                continue;
+            }
+        } else {
+            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+            const uint32_t n = (cur & 7u) + 1u;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float4* r = sv.recs + 3 * (size_t)(first + i);
+                const float4 ra = r[0], rb = r[1], rc = r[2];
+                const rt_f3 v0 = f3(ra.x, ra.y, ra.z);
+                const rt_f3 e1 = f3(ra.w, rb.x, rb.y);
+                const rt_f3 e2 = f3(rb.z, rb.w, rc.x);
+                const uint32_t id = __float_as_uint(rc.y);
+                if (STATS) st.tri += 1;
+                const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+                if (ANY) {
+                    if (!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) return true;
+                } else {
+                    const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
+                    if (!ev.failed && ev.t > 0.0f && better) {
+                        closest = ev.t;
+                        local_best = id;
+                        hit.tri = id;
+                        hit.obj = obj_index;
+                        hit.t = ev.t;
+                        hit.u = ev.u;
+                        hit.v = ev.v;
+                    }
+                }
+            }
+        }
+        // Next pending node whose entry distance is not beyond the current nearest hit.
+        for (;;) {
+            if (stk.sp == 0) return false;
+            const uint2 e = stk.pop();
+            if (!(__uint_as_float(e.y) > closest)) {
+                cur = e.x;
+                break;
+            }
+        }
+    }
+}
+
+// trace_ray's nearest-hit search over the whole World, src/main.rs:93-171.
+template <bool STATS>
+__device__ __forceinline__ HitD closest_all(const SceneView& sv, rt_f3 o, rt_f3 d, LaneStack& stk,
+                                            LaneStats& st) {
+    const rt_f3 inv = g_recip(d);
+    HitD h;
+    h.tri = RT_MISS;
+    h.obj = 0;
+    h.t = h.u = h.v = 0.0f;
+    float closest = RT_INF;
+    if (STATS) st.rays += 1;
+    for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+        const DevObject& ob = sv.objs[oi];
+        if (STATS) st.box += 1;
+        if (!box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) continue;
+        if (ob.root != EMPTY) bvh_search<false, STATS>(sv, ob.root, oi, o, d, inv, closest, h, stk, st);
+        // Trailing n % 8 triangles, src/main.rs:157-169: scalar arithmetic, and `closest` is NOT
+        // lowered by a hit here, so the last qualifying one wins and later objects still compare
+        // against the old distance.
+        for (uint32_t r = 0; r < ob.n_rest; ++r) {
+            const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
+            float t, u, v;
+            if (STATS) st.tri += 1;
+            if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, closest, &t, &u, &v)) {
+                if (closest > t) {
+                    h.tri = ob.tri_base + ob.n_tris - ob.n_rest + r;
+                    h.obj = oi;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                }
+            }
+        }
+    }
+    h.closest = closest;
+    return h;
+}
+
+// trace_ray's shadow search, src/main.rs:185-233. True when anything occludes.
+template <bool STATS>
+__device__ __forceinline__ bool any_all(const SceneView& sv, rt_f3 o, rt_f3 d, LaneStack& stk, LaneStats& st) {
+    const rt_f3 inv = g_recip(d);
+    if (STATS) st.rays += 1;
+    for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+        const DevObject& ob = sv.objs[oi];
+        if (STATS) st.box += 1;
+        if (!box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) continue;
+        if (ob.root != EMPTY) {
+            float closest = RT_INF;
+            HitD dummy;
+            if (bvh_search<true, STATS>(sv, ob.root, oi, o, d, inv, closest, dummy, stk, st)) return true;
+        }
+        for (uint32_t r = 0; r < ob.n_rest; ++r) {
+            const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
+            float t, u, v;
+            if (STATS) st.tri += 1;
+            if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, RT_INF, &t, &u, &v)) return true;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ void flush_stats(const LaneStats& st, DevStats* out) {
+    // One atomic per counter per lane would be heavy; reduce over the wave first.
+    unsigned long long v[4] = {st.rays, st.box, st.tri, st.node};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        v[k] = x;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out->rays, v[0]);
+        atomicAdd(&out->box_tests, v[1]);
+        atomicAdd(&out->tri_tests, v[2]);
+        atomicAdd(&out->node_visits, v[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(SceneView sv, const rt_ray* __restrict__ rays,
+                                                          uint64_t n, rt_hit* __restrict__ out) {
+    __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    LaneStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    LaneStats st;
+    const rt_ray r = rays[i];
+    const HitD h = closest_all<false>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), stk, st);
+    rt_hit o;
+    o.tri = h.tri;
+    o.t = h.t;
+    o.u = h.u;
+    o.v = h.v;
+    out[i] = o;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_any(SceneView sv, const rt_ray* __restrict__ rays,
+                                                      uint64_t n, uint8_t* __restrict__ occluded) {
+    __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    LaneStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    LaneStats st;
+    const rt_ray r = rays[i];
+    occluded[i] = any_all<false>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), stk, st) ? 1 : 0;
+}
+
+// The reference's own visiting order, src/main.rs:100-171: object box, then every 8-wide packet
+// of leaf boxes with the `closest` of the moment, then the leaves that passed, then the leftover
+// leaves and the trailing triangles. All lanes read the same boxes and triangles.
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_linear(SceneView sv, const rt_ray* __restrict__ rays,
+                                                                 uint64_t n, rt_hit* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const rt_ray rr = rays[i];
+    const rt_f3 o = f3(rr.o[0], rr.o[1], rr.o[2]), d = f3(rr.d[0], rr.d[1], rr.d[2]);
+    const rt_f3 inv = g_recip(d);
+    rt_hit h;
+    h.tri = RT_MISS;
+    h.t = h.u = h.v = 0.0f;
+    float closest = RT_INF;
+    for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+        const DevObject& ob = sv.objs[oi];
+        if (!box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) continue;
+        const uint32_t n_leaves = ob.n_packed / 8;
+        const uint32_t n_packets = n_leaves / 8;
+        auto scan_leaf = [&](uint32_t leaf) {
+            // PackedTriangles::intersect with ray_length = closest at entry, then the j loop.
+            const float ray_length = closest;
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t ti = leaf * 8 + j;
+                const float* p = sv.tri9 + 9 * (size_t)(ob.tri_base + ti);
+                const rt_tri_eval ev = tri_intersect(ld3(p), ld3(p + 3), ld3(p + 6), o, d);
+                const bool failed = ev.failed || (ev.t > ray_length);
+                if (!failed && ev.t > 0.0f && closest > ev.t) {
+                    closest = ev.t;
+                    h.tri = ob.tri_base + ti;
+                    h.t = ev.t;
+                    h.u = ev.u;
+                    h.v = ev.v;
+                }
+            }
+        };
+        for (uint32_t pk = 0; pk < n_packets; ++pk) {
+            const float ray_length = closest;  // closest_splat when the packet is tested
+            uint32_t mask = 0;
+            for (uint32_t b = 0; b < 8; ++b) {
+                const float* lb = sv.leaf_bounds + 6 * (size_t)(ob.leaf_base + pk * 8 + b);
+                if (packed_box_hit(ld3(lb), ld3(lb + 3), o, inv, ray_length)) mask |= 1u << b;
+            }
+            for (uint32_t b = 0; b < 8; ++b)
+                if (mask & (1u << b)) scan_leaf(pk * 8 + b);
+        }
+        for (uint32_t l = n_packets * 8; l < n_leaves; ++l) {
+            const float* lb = sv.leaf_bounds + 6 * (size_t)(ob.leaf_base + l);
+            if (box_intersection_check(o, inv, ld3(lb), ld3(lb + 3))) scan_leaf(l);
+        }
+        for (uint32_t r = 0; r < ob.n_rest; ++r) {
+            const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
+            float t, u, v;
+            if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, closest, &t, &u, &v)) {
+                if (closest > t) {
+                    h.tri = ob.tri_base + ob.n_tris - ob.n_rest + r;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                }
+            }
+        }
+    }
+    out[i] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene preparation
+// ---------------------------------------------------------------------------------------------
+// pack_triangles, src/simd_accel.rs:8-66: e1 = b - a, e2 = c - a, v0 = a, one subtraction each.
+__global__ void k_pack_tris(const float* __restrict__ verts, const uint32_t* __restrict__ tris, uint32_t n,
+                            float* __restrict__ tri9) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_f3 a = ld3(verts + 3 * (size_t)tris[3 * (size_t)i]);
+    const rt_f3 b = ld3(verts + 3 * (size_t)tris[3 * (size_t)i + 1]);
+    const rt_f3 c = ld3(verts + 3 * (size_t)tris[3 * (size_t)i + 2]);
+    const rt_f3 e1 = b - a, e2 = c - a;
+    float* o = tri9 + 9 * (size_t)i;
+    o[0] = e1.x; o[1] = e1.y; o[2] = e1.z;
+    o[3] = e2.x; o[4] = e2.y; o[5] = e2.z;
+    o[6] = a.x;  o[7] = a.y;  o[8] = a.z;
+}
+
+// Leaf boxes of pack_model, src/opt.rs:46-60: min / max over the 24 vertices of 8 triangles.
+// leaf_first_tri[l] is the (global, sorted) index of the leaf's first triangle.
+__global__ void k_leaf_bounds(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
+                              const uint32_t* __restrict__ leaf_first_tri, uint32_t n_leaves,
+                              float* __restrict__ leaf_bounds) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_leaves) return;
+    rt_f3 mn = f3(RT_INF, RT_INF, RT_INF), mx = f3(-RT_INF, -RT_INF, -RT_INF);
+    const uint32_t t0 = leaf_first_tri[l];
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t* t = tris + 3 * (size_t)(t0 + j);
+        const rt_f3 a = ld3(verts + 3 * (size_t)t[0]), b = ld3(verts + 3 * (size_t)t[1]),
+                    c = ld3(verts + 3 * (size_t)t[2]);
+        rt_f3 tmn = f3(g_min(g_min(a.x, b.x), c.x), g_min(g_min(a.y, b.y), c.y), g_min(g_min(a.z, b.z), c.z));
+        rt_f3 tmx = f3(g_max(g_max(a.x, b.x), c.x), g_max(g_max(a.y, b.y), c.y), g_max(g_max(a.z, b.z), c.z));
+        mn = f3(g_min(mn.x, tmn.x), g_min(mn.y, tmn.y), g_min(mn.z, tmn.z));
+        mx = f3(g_max(mx.x, tmx.x), g_max(mx.y, tmx.y), g_max(mx.z, tmx.z));
+    }
+    float* o = leaf_bounds + 6 * (size_t)l;
+    o[0] = mn.x; o[1] = mn.y; o[2] = mn.z;
+    o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+}
+
+// Triangle records in tree-leaf order: record r holds triangle order[r] (a global id).
+__global__ void k_gather_records(const float* __restrict__ tri9, const uint32_t* __restrict__ order, uint32_t n,
+                                 float4* __restrict__ recs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t id = order[r];
+    const float* p = tri9 + 9 * (size_t)id;
+    recs[3 * (size_t)r + 0] = make_float4(p[6], p[7], p[8], p[0]);
+    recs[3 * (size_t)r + 1] = make_float4(p[1], p[2], p[3], p[4]);
+    recs[3 * (size_t)r + 2] = make_float4(p[5], __uint_as_float(id), 0.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frame kernel: draw + trace_ray, src/main.rs:88-379.
+// ---------------------------------------------------------------------------------------------
+struct Col {
+    float r, g, b;
+};
+__device__ __forceinline__ Col cmul(Col c, float v) { return Col{c.r * v, c.g * v, c.b * v}; }
+__device__ __forceinline__ Col cmul_col(Col c, Col d) { return Col{c.r * d.r, c.g * d.g, c.b * d.b}; }
+__device__ __forceinline__ Col cadd(Col c, Col d) { return Col{c.r + d.r, c.g + d.g, c.b + d.b}; }
+__device__ __forceinline__ Col cdiv(Col c, float v) { return Col{c.r / v, c.g / v, c.b / v}; }
+// Color::from_u8(0x87, 0xce, 0xeb), src/main.rs:303.
+__device__ __forceinline__ Col sky() { return Col{135.0f / 255.0f, 206.0f / 255.0f, 235.0f / 255.0f}; }
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7feb352du;
+    h ^= h >> 15;
+    h *= 0x846ca68bu;
+    h ^= h >> 16;
+    return h;
+}
+// Counter-based stand-in for rand::random::<f32>() (src/main.rs:262,264): 24 random bits to
+// [0,1), keyed on (seed, sample index, scatter index, which of the two draws).
+__device__ __forceinline__ float counter_rand(uint32_t seed, uint64_t sample_index, uint32_t scatter, uint32_t which) {
+    uint32_t h = mix32(seed ^ 0x9E3779B9u);
+    h = mix32(h ^ (uint32_t)sample_index);
+    h = mix32(h ^ (uint32_t)(sample_index >> 32));
+    h = mix32(h ^ (scatter * 2u + which));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// ScreenColor::from, src/objects.rs:90-97: (c * 255).min(255) as u8 (saturating, NaN -> 255).
+__device__ __forceinline__ uint32_t to_u8(float c) {
+    float v = g_min(c * 255.0f, 255.0f);
+    if (!(v > 0.0f)) return 0u;
+    return (uint32_t)v;
+}
+
+struct Surface {
+    rt_f3 pos;     // hit position offset along the stored normal, src/main.rs:121-124
+    rt_f3 normal;
+    Col color;
+    float albedo, reflectivity, roughness;
+};
+
+__device__ __forceinline__ Surface surface_of(const SceneView& sv, const HitD& h, rt_f3 o, rt_f3 d) {
+    const float* td = sv.tri_data + 6 * (size_t)h.tri;
+    Surface s;
+    s.normal = ld3(td);
+    s.color = Col{td[3], td[4], td[5]};
+    s.pos = (o + d * h.t) + (s.normal * 0.00001f);
+    const DevObject& ob = sv.objs[h.obj];
+    s.albedo = ob.albedo;
+    s.reflectivity = ob.reflectivity;
+    s.roughness = ob.roughness;
+    return s;
+}
+
+// Direct sun light at a surface, src/main.rs:176-241.
+template <bool STATS>
+__device__ __forceinline__ Col direct_light(const SceneView& sv, const Surface& s, rt_f3 sun, LaneStack& stk,
+                                            LaneStats& st) {
+    const rt_f3 sun_dir = g_normalize(sun - s.pos);
+    Col c{0.0f, 0.0f, 0.0f};
+    if (g_dot(s.normal, sun_dir) > 0.0f) {
+        if (!any_all<STATS>(sv, s.pos, sun_dir, stk, st)) {
+            const float light_power = g_dot(s.normal, sun_dir);
+            c = cmul(s.color, light_power * s.albedo);
+        }
+    }
+    return c;
+}
+
+// trace_ray for a ray at `depth` when no diffuse scattering happens at this depth or below
+// (depth >= DIFFUSE_DEPTH): the recursion is a chain of mirror bounces, src/main.rs:243-257,
+// folded back in the reference's order: color = direct + col * reflectivity.
+template <bool STATS>
+__device__ __forceinline__ Col mirror_chain(const SceneView& sv, const DevRenderParams& p, rt_f3 o, rt_f3 d,
+                                            uint32_t depth, uint32_t* first_hit, LaneStack& stk, LaneStats& st) {
+    Col direct[RT_MAX_REFLECT];
+    float refl[RT_MAX_REFLECT];
+    int n = 0;
+    Col tail;
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    for (;;) {
+        const HitD h = closest_all<STATS>(sv, o, d, stk, st);
+        if (first_hit) {
+            *first_hit = h.tri;
+            first_hit = nullptr;
+        }
+        if (h.tri == RT_MISS) {
+            tail = sky();
+            break;
+        }
+        const Surface s = surface_of(sv, h, o, d);
+        const Col c = direct_light<STATS>(sv, s, sun, stk, st);
+        if (depth < p.reflect_depth && s.reflectivity > 0.0f && n < RT_MAX_REFLECT) {
+            direct[n] = c;
+            refl[n] = s.reflectivity;
+            ++n;
+            const rt_f3 rd = d - 2.0f * s.normal * g_dot(d, s.normal);
+            o = s.pos;
+            d = rd;
+            ++depth;
+            continue;
+        }
+        tail = c;
+        break;
+    }
+    for (int i = n - 1; i >= 0; --i) tail = cadd(direct[i], cmul(tail, refl[i]));
+    return tail;
+}
+
+// get_tangent_vectors, src/main.rs:74-86.
+__device__ __forceinline__ void tangent_vectors(rt_f3 n, rt_f3* t1, rt_f3* t2) {
+    const rt_f3 arbitrary = (__builtin_fabsf(n.z) < 1e-6f) ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
+    *t1 = g_normalize(g_cross(n, arbitrary));
+    *t2 = g_normalize(g_cross(n, *t1));
+}
+
+// Sub-sample offsets: grid 2 is the reference's fixed order, src/main.rs:322-364.
+__device__ __forceinline__ void sample_offset(uint32_t grid, uint32_t s, float* ox, float* oy) {
+    if (grid == 2) {
+        *ox = (s & 1u) ? 0.75f : 0.25f;
+        *oy = (s == 1u || s == 2u) ? 0.75f : 0.25f;
+    } else {
+        *ox = ((float)(s % grid) + 0.5f) / (float)grid;
+        *oy = ((float)(s / grid) + 0.5f) / (float)grid;
+    }
+}
+
+// One lane per sub-sample. A workgroup covers 256 / spp pixels of one tile (a square block in
+// Morton order, so a wave's rays stay close together); the samples of a pixel sit in
+// consecutive lanes and are averaged through LDS in the reference's order.
+template <bool BOUNCES, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_render(SceneView sv, DevRenderParams p,
+                                                     const uint32_t* __restrict__ tile_list,
+                                                     uint8_t* __restrict__ rgba8, uint32_t* __restrict__ hit_ids,
+                                                     DevStats* __restrict__ stats) {
+    __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ float s_col[3 * RT_BLOCK];
+    const uint32_t spp = p.spp;
+    const uint32_t ppb = RT_BLOCK / spp;                         // pixels per workgroup
+    const uint32_t blocks_per_tile = (RT_TILE * RT_TILE) / ppb;
+    const uint32_t local_tile = blockIdx.x / blocks_per_tile;
+    const uint32_t block_in_tile = blockIdx.x % blocks_per_tile;
+    const uint32_t tile = tile_list ? tile_list[local_tile] : local_tile;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t s = threadIdx.x % spp;
+    const uint32_t pix_in_tile = block_in_tile * ppb + threadIdx.x / spp;  // Morton index in the tile
+    uint32_t mx = 0, my = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        mx |= ((pix_in_tile >> (2 * b)) & 1u) << b;
+        my |= ((pix_in_tile >> (2 * b + 1)) & 1u) << b;
+    }
+    const uint32_t x = tx * RT_TILE + mx, y = ty * RT_TILE + my;
+    const bool inside = x < p.width && y < p.height;
+
+    LaneStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    LaneStats st;
+    Col color{0.0f, 0.0f, 0.0f};
+    if (inside) {
+        float ox, oy;
+        sample_offset(p.grid, s, &ox, &oy);
+        // src/main.rs:314,322-330. aspect_ratio is an integer division in the reference.
+        const float aspect = (float)(p.width / p.height);
+        const float xx = (2.0f * ((float)x + ox) / (float)p.width - 1.0f) * aspect * 1.0f;
+        const float yy = (1.0f - 2.0f * ((float)y + oy) / (float)p.height) * 1.0f;
+        const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(xx, yy, 1.0f);
+        const uint64_t pix = (uint64_t)y * p.width + x;
+        const uint64_t sample_index = pix * spp + s;
+        uint32_t primary = RT_MISS;
+        bool hit_any;
+        if (!BOUNCES || p.diffuse_depth <= 1) {
+            color = mirror_chain<STATS>(sv, p, o, d, 1, &primary, stk, st);
+            hit_any = primary != RT_MISS;
+        } else {
+            // depth 1 with diffuse scattering, src/main.rs:173-301.
+            const HitD h = closest_all<STATS>(sv, o, d, stk, st);
+            primary = h.tri;
+            hit_any = h.tri != RT_MISS;
+            if (!hit_any) {
+                color = sky();
+            } else {
+                const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+                const Surface sf = surface_of(sv, h, o, d);
+                color = direct_light<STATS>(sv, sf, sun, stk, st);
+                Col reflect_color{0.0f, 0.0f, 0.0f};
+                if (1u < p.reflect_depth && sf.reflectivity > 0.0f) {
+                    const rt_f3 rd = d - 2.0f * sf.normal * g_dot(d, sf.normal);
+                    reflect_color = cmul(mirror_chain<STATS>(sv, p, sf.pos, rd, 2, nullptr, stk, st), sf.reflectivity);
+                }
+                Col diffuse_color{0.0f, 0.0f, 0.0f};
+                rt_f3 tang1, tang2;
+                tangent_vectors(sf.normal, &tang1, &tang2);
+                for (uint32_t k = 0; k < p.diffuse_scatt; ++k) {
+                    const float sin_theta = __builtin_sqrtf(counter_rand(p.seed, sample_index, k, 0));
+                    const float cos_theta = __builtin_sqrtf(1.0f - sin_theta * sin_theta);
+                    const float psi = counter_rand(p.seed, sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
+                    const float a = sin_theta * cosf(psi);
+                    const float b = sin_theta * sinf(psi);
+                    const float c = cos_theta;
+                    const rt_f3 vel = g_normalize(f3(a * tang1.x + b * tang2.x + c * sf.normal.x,
+                                                     a * tang1.y + b * tang2.y + c * sf.normal.y,
+                                                     a * tang1.z + b * tang2.z + c * sf.normal.z));
+                    const float light_power = g_dot(sf.normal, vel);
+                    const Col col = mirror_chain<STATS>(sv, p, sf.pos, vel, 2, nullptr, stk, st);
+                    diffuse_color = cadd(diffuse_color, cmul(cmul_col(col, sf.color), light_power * sf.roughness));
+                }
+                diffuse_color = cdiv(diffuse_color, (float)p.diffuse_scatt);
+                color = cadd(color, reflect_color);
+                color = cadd(color, diffuse_color);
+            }
+        }
+        // Gamma only for samples that hit something, src/main.rs:302-310.
+        if (hit_any) color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+        if (hit_ids) hit_ids[sample_index] = primary;
+    }
+    if (STATS) flush_stats(st, stats);
+
+    // Average the pixel's samples in order (c1 + c2 + c3 + c4) / n, src/main.rs:365.
+    s_col[3 * threadIdx.x + 0] = color.r;
+    s_col[3 * threadIdx.x + 1] = color.g;
+    s_col[3 * threadIdx.x + 2] = color.b;
+    __syncthreads();
+    if (s == 0 && inside) {
+        Col acc = color;
+        for (uint32_t k = 1; k < spp; ++k) {
+            const float* c = &s_col[3 * (threadIdx.x + k)];
+            acc = cadd(acc, Col{c[0], c[1], c[2]});
+        }
+        acc = cdiv(acc, (float)spp);
+        const uint32_t px = to_u8(acc.r) | (to_u8(acc.g) << 8) | (to_u8(acc.b) << 16) | 0xff000000u;
+        size_t off;
+        if (p.compact) off = ((size_t)local_tile * RT_TILE * RT_TILE + (size_t)my * RT_TILE + mx) * 4;
+        else off = ((size_t)y * p.width + x) * 4;
+        *reinterpret_cast<uint32_t*>(rgba8 + off) = px;
+    }
+}
+
+// Scatter of gathered tile-compact slabs into a frame. Tile t belongs to shard (tx + ty) % count;
+// its slot inside the shard's slab is its rank among that shard's tiles in ascending tile id,
+// given by tile_slot[t].
+__global__ void k_deinterleave(const uint8_t* __restrict__ gathered, const uint32_t* __restrict__ tile_slot,
+                               uint32_t slab_tiles, uint32_t width, uint32_t height, uint32_t tiles_x,
+                               uint32_t shard_count, uint8_t* __restrict__ rgba8) {
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t shard = (tx + ty) % shard_count;
+    const uint32_t slot = tile_slot[tile];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gathered) +
+                          ((size_t)shard * slab_tiles + slot) * RT_TILE * RT_TILE;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(rgba8);
+    for (uint32_t i = threadIdx.x; i < RT_TILE * RT_TILE; i += blockDim.x) {
+        const uint32_t lx = i % RT_TILE, ly = i / RT_TILE;
+        const uint32_t x = tx * RT_TILE + lx, y = ty * RT_TILE + ly;
+        if (x < width && y < height) dst[(size_t)y * width + x] = src[i];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------
+namespace rtk {
+
+static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_occ);
+    return hipGetLastError();
+}
+
+hipError_t trace_closest_linear(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
+                                hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_closest_linear, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n,
+                       d_out);
+    return hipGetLastError();
+}
+
+hipError_t pack_tris(const float* d_verts, const uint32_t* d_tris, uint32_t n, float* d_tri9, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_tris, dim3(grid_for(n, 256)), dim3(256), 0, s, d_verts, d_tris, n, d_tri9);
+    return hipGetLastError();
+}
+
+hipError_t leaf_bounds(const float* d_verts, const uint32_t* d_tris, const uint32_t* d_leaf_first, uint32_t n_leaves,
+                       float* d_leaf_bounds, hipStream_t s) {
+    if (n_leaves == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_leaf_bounds, dim3(grid_for(n_leaves, 256)), dim3(256), 0, s, d_verts, d_tris, d_leaf_first,
+                       n_leaves, d_leaf_bounds);
+    return hipGetLastError();
+}
+
+hipError_t gather_records(const float* d_tri9, const uint32_t* d_order, uint32_t n, float4* d_recs, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_records, dim3(grid_for(n, 256)), dim3(256), 0, s, d_tri9, d_order, n, d_recs);
+    return hipGetLastError();
+}
+
+hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, bool bounces,
+                  uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats, hipStream_t s) {
+    const uint32_t ppb = RT_BLOCK / p.spp;
+    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / ppb);
+    if (blocks == 0) return hipSuccess;
+    if (d_stats) {
+        if (bounces)
+            hipLaunchKernelGGL((k_render<true, true>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_rgba8,
+                               d_hit_ids, d_stats);
+        else
+            hipLaunchKernelGGL((k_render<false, true>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list,
+                               d_rgba8, d_hit_ids, d_stats);
+    } else {
+        if (bounces)
+            hipLaunchKernelGGL((k_render<true, false>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list,
+                               d_rgba8, d_hit_ids, d_stats);
+        else
+            hipLaunchKernelGGL((k_render<false, false>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list,
+                               d_rgba8, d_hit_ids, d_stats);
+    }
+    return hipGetLastError();
+}
+
+hipError_t deinterleave(const uint8_t* d_gathered, const uint32_t* d_tile_slot, uint32_t slab_tiles, uint32_t width,
+                        uint32_t height, uint32_t tiles_x, uint32_t n_tiles_total, uint32_t shard_count,
+                        uint8_t* d_rgba8, hipStream_t s) {
+    if (n_tiles_total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_deinterleave, dim3(n_tiles_total), dim3(256), 0, s, d_gathered, d_tile_slot, slab_tiles,
+                       width, height, tiles_x, shard_count, d_rgba8);
+    return hipGetLastError();
+}
+
+}  // namespace rtk
