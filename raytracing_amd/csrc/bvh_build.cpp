@@ -260,22 +260,26 @@ struct Collapser {
         for (int i = 0; i < 4; ++i) {
             if (i < nk) {
                 const Node2& c = b.nodes_[kids[i]];
-                n4.lox[i] = c.lo[0]; n4.loy[i] = c.lo[1]; n4.loz[i] = c.lo[2];
-                n4.hix[i] = c.hi[0]; n4.hiy[i] = c.hi[1]; n4.hiz[i] = c.hi[2];
+                for (int k = 0; k < 3; ++k) {
+                    n4.c[i].lo[k] = c.lo[k];
+                    n4.c[i].hi[k] = c.hi[k];
+                }
                 if (c.count > 0) {
-                    n4.child[i] = emit_leaf(c);
+                    n4.c[i].ref = emit_leaf(c);
                 } else {
                     uint32_t ci;
                     uint32_t d = emit_inner(kids[i], &ci);
-                    n4.child[i] = node_base + ci;
+                    n4.c[i].ref = node_base + ci;
                     deepest = std::max(deepest, d);
                 }
             } else {
                 // An inverted box: every slab test on it fails for finite rays; the kernels also
                 // check the reference itself.
-                n4.lox[i] = n4.loy[i] = n4.loz[i] = INFINITY;
-                n4.hix[i] = n4.hiy[i] = n4.hiz[i] = -INFINITY;
-                n4.child[i] = EMPTY;
+                for (int k = 0; k < 3; ++k) {
+                    n4.c[i].lo[k] = INFINITY;
+                    n4.c[i].hi[k] = -INFINITY;
+                }
+                n4.c[i].ref = EMPTY;
             }
         }
         out.nodes[me] = n4;
@@ -314,14 +318,18 @@ void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32
         Node4 n4;
         std::memset(&n4, 0, sizeof(n4));
         for (int i = 0; i < 4; ++i) {
-            n4.lox[i] = n4.loy[i] = n4.loz[i] = INFINITY;
-            n4.hix[i] = n4.hiy[i] = n4.hiz[i] = -INFINITY;
-            n4.child[i] = EMPTY;
+            for (int k = 0; k < 3; ++k) {
+                n4.c[i].lo[k] = INFINITY;
+                n4.c[i].hi[k] = -INFINITY;
+            }
+            n4.c[i].ref = EMPTY;
         }
-        n4.lox[0] = r.lo[0]; n4.loy[0] = r.lo[1]; n4.loz[0] = r.lo[2];
-        n4.hix[0] = r.hi[0]; n4.hiy[0] = r.hi[1]; n4.hiz[0] = r.hi[2];
+        for (int k = 0; k < 3; ++k) {
+            n4.c[0].lo[k] = r.lo[k];
+            n4.c[0].hi[k] = r.hi[k];
+        }
         out->nodes.push_back(n4);
-        out->nodes[0].child[0] = c.emit_leaf(r);
+        out->nodes[0].c[0].ref = c.emit_leaf(r);
         out->max_stack = 1;
     } else {
         uint32_t ri;

@@ -11,15 +11,18 @@
 
 namespace rtbvh {
 
-// One 128-byte node: four child boxes in SoA form plus four child references.
-//   child[k] == EMPTY              : slot unused
-//   child[k] &  LEAF_BIT           : leaf; bits 3..30 = first triangle record, bits 0..2 = count-1
-//   otherwise                      : index of an inner node
+// One 128-byte node: four children of 32 bytes each (box, reference, padding), so that one
+// child is one 8-dword load and the node is one cache line.
+//   ref == EMPTY              : slot unused
+//   ref &  LEAF_BIT           : leaf; bits 3..30 = first triangle record, bits 0..2 = count-1
+//   otherwise                 : index of an inner node
+struct Child {
+    float lo[3], hi[3];
+    uint32_t ref;
+    uint32_t pad;
+};
 struct Node4 {
-    float lox[4], loy[4], loz[4];
-    float hix[4], hiy[4], hiz[4];
-    uint32_t child[4];
-    uint32_t pad[4];
+    Child c[4];
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
 

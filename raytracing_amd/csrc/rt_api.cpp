@@ -186,8 +186,10 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         dp.n_tiles = dp.tiles_x * ceil_div(p->height, RT_TILE);
         dp.compact = 0;
     }
-    const bool bounces = p->diffuse_depth > 1;
-    HIP_TRY(rtk::render(s->view, dp, d_list, bounces, d_rgba8, d_hit_ids, d_stats, stream));
+    bool reflective = false;
+    for (const DevObject& ob : s->objects) reflective = reflective || ob.reflectivity > 0.0f;
+    const int mode = p->diffuse_depth > 1 ? 2 : ((reflective && p->reflect_depth > 1) ? 1 : 0);
+    HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
     return RT_OK;
 }
 

@@ -80,28 +80,29 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
     for (;;) {
         if (!(cur & LEAF_BIT)) {
             const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
-            const float4 lox = np[0], loy = np[1], loz = np[2];
-            const float4 hix = np[3], hiy = np[4], hiz = np[5];
-            const uint4 ch = *reinterpret_cast<const uint4*>(np + 6);
+            // child k = (lo.x lo.y lo.z hi.x) (hi.y hi.z ref pad)
+            const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3];
+            const float4 a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
             if (STATS) {
                 st.node += 1;
                 st.box += 4;
             }
             float k0, k1, k2, k3;
-            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-#define RT_BOX(K, C, LX, LY, LZ, HX, HY, HZ)                                                        \
+            uint32_t c0 = __float_as_uint(b0.z), c1 = __float_as_uint(b1.z);
+            uint32_t c2 = __float_as_uint(b2.z), c3 = __float_as_uint(b3.z);
+#define RT_BOX(K, C, A, B)                                                                           \
     {                                                                                                \
-        float ax = __builtin_fmaf(LX, inv.x, nox), bx = __builtin_fmaf(HX, inv.x, nox);              \
-        float ay = __builtin_fmaf(LY, inv.y, noy), by = __builtin_fmaf(HY, inv.y, noy);              \
-        float az = __builtin_fmaf(LZ, inv.z, noz), bz = __builtin_fmaf(HZ, inv.z, noz);              \
+        float ax = __builtin_fmaf(A.x, inv.x, nox), bx = __builtin_fmaf(A.w, inv.x, nox);            \
+        float ay = __builtin_fmaf(A.y, inv.y, noy), by = __builtin_fmaf(B.x, inv.y, noy);            \
+        float az = __builtin_fmaf(A.z, inv.z, noz), bz = __builtin_fmaf(B.y, inv.z, noz);            \
         float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));           \
         float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));        \
         K = ((C) != EMPTY && tn <= tf) ? tn : RT_INF;                                                \
     }
-            RT_BOX(k0, c0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x)
-            RT_BOX(k1, c1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y)
-            RT_BOX(k2, c2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z)
-            RT_BOX(k3, c3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w)
+            RT_BOX(k0, c0, a0, b0)
+            RT_BOX(k1, c1, a1, b1)
+            RT_BOX(k2, c2, a2, b2)
+            RT_BOX(k3, c3, a3, b3)
 #undef RT_BOX
             RT_CSWAP(k0, k1, c0, c1)
             RT_CSWAP(k2, k3, c2, c3)
@@ -215,6 +216,266 @@ __device__ __forceinline__ bool any_all(const SceneView& sv, rt_f3 o, rt_f3 d, L
         }
     }
     return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-coherent ("packet") traversal: the 64 rays of a wave walk one object's tree together.
+// The node is fetched once per wave through the scalar cache (uniform address, constant address
+// space -> s_load), each lane tests its own ray against the four child boxes with the node held
+// in SGPRs, and wave ballots decide which children the wave visits. The pending-node stack is
+// shared by the wave and lives in two VGPRs (entry i in lane i), so there is no LDS or memory
+// traffic for it. Every lane tests every triangle of every leaf the wave reaches whose box its
+// own ray hits; results per lane are the same as in the per-lane walk because the nearest hit
+// does not depend on the visiting order.
+// Meant for rays that start close together and point the same way (camera rays of neighbouring
+// pixels, their sun shadow rays); correct for any rays, slower than the per-lane walk for
+// incoherent ones.
+// ---------------------------------------------------------------------------------------------
+#define RT_CONST __attribute__((address_space(4)))
+// Declared with 4-byte alignment: triangle records (48 B) and trailing-triangle vertices (36 B)
+// are not multiples of the vector size, and scalar loads only need dword alignment.
+typedef float f32x4_t __attribute__((ext_vector_type(4))) __attribute__((aligned(4)));
+typedef float f32x8_t __attribute__((ext_vector_type(8))) __attribute__((aligned(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16))) __attribute__((aligned(4)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ f32x4_t sload4(const void* p) { return *(const RT_CONST f32x4_t*)p; }
+__device__ __forceinline__ f32x8_t sload8(const void* p) { return *(const RT_CONST f32x8_t*)p; }
+__device__ __forceinline__ f32x16_t sload16(const void* p) { return *(const RT_CONST f32x16_t*)p; }
+__device__ __forceinline__ uint32_t sload1u(const void* p) { return *(const RT_CONST uint32_t*)p; }
+#pragma clang diagnostic pop
+
+#define RT_INF_BITS 0x7f800000
+#define RT_BALLOT(pred) __ballot(pred)
+
+// Wave-shared stack of at most 128 node references: entry i is lane (i & 63) of r0 / r1.
+struct WaveStack {
+    int r0 = 0, r1 = 0;
+    int sp = 0;  // wave-uniform
+    __device__ __forceinline__ void push(int lane, uint32_t v) {
+        if (sp < 64) r0 = (lane == sp) ? (int)v : r0;
+        else r1 = (lane == sp - 64) ? (int)v : r1;
+        sp = sp < 2 * 64 - 1 ? sp + 1 : sp;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        --sp;
+        return (uint32_t)(sp < 64 ? __builtin_amdgcn_readlane(r0, sp) : __builtin_amdgcn_readlane(r1, sp - 64));
+    }
+};
+
+#define RT_SSWAP(ka, kb, ca, cb)  \
+    if ((ka) > (kb)) {            \
+        int tk_ = (ka);           \
+        (ka) = (kb);              \
+        (kb) = tk_;               \
+        uint32_t tc_ = (ca);      \
+        (ca) = (cb);              \
+        (cb) = tc_;               \
+    }
+
+// One leaf (wave-uniform reference) against every lane with `pred` set.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, uint32_t obj_index, bool pred, rt_f3 o,
+                                            rt_f3 d, float& closest, uint32_t& local_best, HitD& hit, bool& active,
+                                            bool& occluded, LaneStats& st) {
+    const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
+    const uint32_t n = (ref & 7u) + 1u;
+    for (uint32_t i = 0; i < n; ++i) {
+        const char* rp = reinterpret_cast<const char*>(sv.recs) + 48 * (size_t)(first + i);
+        const f32x8_t ra = sload8(rp);
+        const f32x4_t rb = sload4(rp + 32);
+        const rt_f3 v0 = f3(ra[0], ra[1], ra[2]);
+        const rt_f3 e1 = f3(ra[3], ra[4], ra[5]);
+        const rt_f3 e2 = f3(ra[6], ra[7], rb[0]);
+        const uint32_t id = __float_as_uint(rb[1]);
+        if (STATS && pred) st.tri += 1;
+        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+        if (ANY) {
+            if (pred && !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) {
+                occluded = true;
+                active = false;
+                pred = false;
+            }
+        } else {
+            const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
+            if (pred && !ev.failed && ev.t > 0.0f && better) {
+                closest = ev.t;
+                local_best = id;
+                hit.tri = id;
+                hit.obj = obj_index;
+                hit.t = ev.t;
+                hit.u = ev.u;
+                hit.v = ev.v;
+            }
+        }
+    }
+}
+
+// Walks one object's tree for the whole wave. `active` marks the lanes whose rays take part.
+// Acceptance rules are those of bvh_search.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ void packet_search(const SceneView& sv, uint32_t root, uint32_t obj_index, rt_f3 o, rt_f3 d,
+                                              rt_f3 inv, bool active, float& closest, HitD& hit, bool& occluded,
+                                              LaneStats& st) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
+    uint32_t local_best = 0;
+    WaveStack stk;
+    uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)root);
+    for (;;) {
+        if (ANY) {
+            if (RT_BALLOT(active) == 0ull) break;
+        }
+        const char* np = reinterpret_cast<const char*>(sv.nodes) + 128 * (size_t)cur;
+        const f32x16_t A = sload16(np);
+        const f32x16_t B = sload16(np + 64);
+        if (STATS && active) {
+            st.node += 1;
+            st.box += 4;
+        }
+        float tn0, tn1, tn2, tn3;
+        bool h0, h1, h2, h3;
+        uint32_t c0 = __float_as_uint(A[6]), c1 = __float_as_uint(A[14]);
+        uint32_t c2 = __float_as_uint(B[6]), c3 = __float_as_uint(B[14]);
+#define RT_PBOX(TN, H, C, V, O)                                                                          \
+    {                                                                                                    \
+        float ax = __builtin_fmaf(V[O + 0], inv.x, nox), bx = __builtin_fmaf(V[O + 3], inv.x, nox);      \
+        float ay = __builtin_fmaf(V[O + 1], inv.y, noy), by = __builtin_fmaf(V[O + 4], inv.y, noy);      \
+        float az = __builtin_fmaf(V[O + 2], inv.z, noz), bz = __builtin_fmaf(V[O + 5], inv.z, noz);      \
+        TN = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));                     \
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));            \
+        H = active && (C) != EMPTY && TN <= tf;                                                          \
+    }
+        RT_PBOX(tn0, h0, c0, A, 0)
+        RT_PBOX(tn1, h1, c1, A, 8)
+        RT_PBOX(tn2, h2, c2, B, 0)
+        RT_PBOX(tn3, h3, c3, B, 8)
+#undef RT_PBOX
+        // Leaves first: they are cheap and shorten `closest` before any subtree is entered.
+        if ((c0 & LEAF_BIT) && c0 != EMPTY && RT_BALLOT(h0) != 0ull)
+            packet_leaf<ANY, STATS>(sv, c0, obj_index, h0, o, d, closest, local_best, hit, active, occluded, st);
+        if ((c1 & LEAF_BIT) && c1 != EMPTY && RT_BALLOT(h1) != 0ull)
+            packet_leaf<ANY, STATS>(sv, c1, obj_index, h1 && active, o, d, closest, local_best, hit, active, occluded, st);
+        if ((c2 & LEAF_BIT) && c2 != EMPTY && RT_BALLOT(h2) != 0ull)
+            packet_leaf<ANY, STATS>(sv, c2, obj_index, h2 && active, o, d, closest, local_best, hit, active, occluded, st);
+        if ((c3 & LEAF_BIT) && c3 != EMPTY && RT_BALLOT(h3) != 0ull)
+            packet_leaf<ANY, STATS>(sv, c3, obj_index, h3 && active, o, d, closest, local_best, hit, active, occluded, st);
+        // Inner children some lane still needs, keyed by the entry distance of the first such lane.
+        int k0 = RT_INF_BITS, k1 = RT_INF_BITS, k2 = RT_INF_BITS, k3 = RT_INF_BITS;
+        {
+            unsigned long long m;
+            if (!(c0 & LEAF_BIT) && (m = RT_BALLOT(h0 && active && tn0 <= closest)) != 0ull)
+                k0 = __builtin_amdgcn_readlane(__float_as_int(tn0), __builtin_ctzll(m));
+            if (!(c1 & LEAF_BIT) && (m = RT_BALLOT(h1 && active && tn1 <= closest)) != 0ull)
+                k1 = __builtin_amdgcn_readlane(__float_as_int(tn1), __builtin_ctzll(m));
+            if (!(c2 & LEAF_BIT) && (m = RT_BALLOT(h2 && active && tn2 <= closest)) != 0ull)
+                k2 = __builtin_amdgcn_readlane(__float_as_int(tn2), __builtin_ctzll(m));
+            if (!(c3 & LEAF_BIT) && (m = RT_BALLOT(h3 && active && tn3 <= closest)) != 0ull)
+                k3 = __builtin_amdgcn_readlane(__float_as_int(tn3), __builtin_ctzll(m));
+        }
+        // Entry distances are >= 0, so their bit patterns order like integers.
+        RT_SSWAP(k0, k1, c0, c1)
+        RT_SSWAP(k2, k3, c2, c3)
+        RT_SSWAP(k0, k2, c0, c2)
+        RT_SSWAP(k1, k3, c1, c3)
+        RT_SSWAP(k1, k2, c1, c2)
+        if (k3 < RT_INF_BITS) stk.push(lane, c3);
+        if (k2 < RT_INF_BITS) stk.push(lane, c2);
+        if (k1 < RT_INF_BITS) stk.push(lane, c1);
+        if (k0 < RT_INF_BITS) {
+            cur = c0;
+            continue;
+        }
+        if (stk.sp == 0) break;
+        cur = stk.pop();
+    }
+}
+
+// The wave-coherent forms of closest_all / any_all. Every lane of the wave must call them
+// together; `active` says whether the lane carries a ray.
+template <bool STATS>
+__device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, LaneStats& st) {
+    const rt_f3 inv = g_recip(d);
+    HitD h;
+    h.tri = RT_MISS;
+    h.obj = 0;
+    h.t = h.u = h.v = 0.0f;
+    float closest = RT_INF;
+    if (STATS && active) st.rays += 1;
+    bool unused = false;
+    for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+        const char* op = reinterpret_cast<const char*>(sv.objs) + 64 * (size_t)oi;
+        const f32x16_t ob = sload16(op);
+        const rt_f3 bbmin = f3(ob[0], ob[1], ob[2]), bbmax = f3(ob[3], ob[4], ob[5]);
+        const uint32_t tri_base = __float_as_uint(ob[6]), n_tris = __float_as_uint(ob[7]);
+        const uint32_t root = __float_as_uint(ob[9]);
+        const uint32_t rest_base = __float_as_uint(ob[10]), n_rest = __float_as_uint(ob[11]);
+        if (STATS && active) st.box += 1;
+        const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
+        if (RT_BALLOT(in_obj) == 0ull) continue;
+        if (root != EMPTY) packet_search<false, STATS>(sv, root, oi, o, d, inv, in_obj, closest, h, unused, st);
+        for (uint32_t r = 0; r < n_rest; ++r) {
+            const char* pv = reinterpret_cast<const char*>(sv.rest_verts) + 36 * (size_t)(rest_base + r);
+            const f32x8_t va = sload8(pv);
+            const float vc2 = __uint_as_float(sload1u(pv + 32));
+            float t, u, v;
+            if (STATS && in_obj) st.tri += 1;
+            if (in_obj && triangle_ray_hits(f3(va[0], va[1], va[2]), f3(va[3], va[4], va[5]), f3(va[6], va[7], vc2), o,
+                                            d, closest, &t, &u, &v)) {
+                if (closest > t) {
+                    h.tri = tri_base + n_tris - n_rest + r;
+                    h.obj = oi;
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                }
+            }
+        }
+    }
+    h.closest = closest;
+    return h;
+}
+
+template <bool STATS>
+__device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, LaneStats& st) {
+    const rt_f3 inv = g_recip(d);
+    if (STATS && active) st.rays += 1;
+    bool occluded = false;
+    for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+        if (RT_BALLOT(active) == 0ull) break;
+        const char* op = reinterpret_cast<const char*>(sv.objs) + 64 * (size_t)oi;
+        const f32x16_t ob = sload16(op);
+        const rt_f3 bbmin = f3(ob[0], ob[1], ob[2]), bbmax = f3(ob[3], ob[4], ob[5]);
+        const uint32_t root = __float_as_uint(ob[9]);
+        const uint32_t rest_base = __float_as_uint(ob[10]), n_rest = __float_as_uint(ob[11]);
+        if (STATS && active) st.box += 1;
+        const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
+        if (RT_BALLOT(in_obj) == 0ull) continue;
+        if (root != EMPTY) {
+            float closest = RT_INF;
+            HitD dummy;
+            bool occ = false;
+            packet_search<true, STATS>(sv, root, oi, o, d, inv, in_obj, closest, dummy, occ, st);
+            if (occ) {
+                occluded = true;
+                active = false;
+            }
+        }
+        for (uint32_t r = 0; r < n_rest; ++r) {
+            const char* pv = reinterpret_cast<const char*>(sv.rest_verts) + 36 * (size_t)(rest_base + r);
+            const f32x8_t va = sload8(pv);
+            const float vc2 = __uint_as_float(sload1u(pv + 32));
+            float t, u, v;
+            const bool test = in_obj && active;
+            if (STATS && test) st.tri += 1;
+            if (test && triangle_ray_hits(f3(va[0], va[1], va[2]), f3(va[3], va[4], va[5]), f3(va[6], va[7], vc2), o, d,
+                                          RT_INF, &t, &u, &v)) {
+                occluded = true;
+                active = false;
+            }
+        }
+    }
+    return occluded;
 }
 
 __device__ __forceinline__ void flush_stats(const LaneStats& st, DevStats* out) {
@@ -464,7 +725,7 @@ __device__ __forceinline__ Col direct_light(const SceneView& sv, const Surface& 
 // folded back in the reference's order: color = direct + col * reflectivity.
 template <bool STATS>
 __device__ __forceinline__ Col mirror_chain(const SceneView& sv, const DevRenderParams& p, rt_f3 o, rt_f3 d,
-                                            uint32_t depth, uint32_t* first_hit, LaneStack& stk, LaneStats& st) {
+                                            uint32_t depth, LaneStack& stk, LaneStats& st) {
     Col direct[RT_MAX_REFLECT];
     float refl[RT_MAX_REFLECT];
     int n = 0;
@@ -472,10 +733,6 @@ __device__ __forceinline__ Col mirror_chain(const SceneView& sv, const DevRender
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
     for (;;) {
         const HitD h = closest_all<STATS>(sv, o, d, stk, st);
-        if (first_hit) {
-            *first_hit = h.tri;
-            first_hit = nullptr;
-        }
         if (h.tri == RT_MISS) {
             tail = sky();
             break;
@@ -520,12 +777,16 @@ __device__ __forceinline__ void sample_offset(uint32_t grid, uint32_t s, float* 
 // One lane per sub-sample. A workgroup covers 256 / spp pixels of one tile (a square block in
 // Morton order, so a wave's rays stay close together); the samples of a pixel sit in
 // consecutive lanes and are averaged through LDS in the reference's order.
-template <bool BOUNCES, bool STATS>
+// Camera rays and their sun shadow rays are traced wave-coherently (packet_search); mirror and
+// diffuse bounces, which scatter, are traced per lane.
+// MODE 0: camera + shadow rays only (no reflective object or reflect_depth <= 1, diffuse_depth <= 1)
+// MODE 1: + mirror chains     MODE 2: + diffuse scattering at depth 1
+template <int MODE, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_render(SceneView sv, DevRenderParams p,
                                                      const uint32_t* __restrict__ tile_list,
                                                      uint8_t* __restrict__ rgba8, uint32_t* __restrict__ hit_ids,
                                                      DevStats* __restrict__ stats) {
-    __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint2 s_stack[MODE > 0 ? RT_STACK_LDS * RT_BLOCK : 1];
     __shared__ float s_col[3 * RT_BLOCK];
     const uint32_t spp = p.spp;
     const uint32_t ppb = RT_BLOCK / spp;                         // pixels per workgroup
@@ -546,66 +807,64 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(SceneView sv, DevRenderPara
     const bool inside = x < p.width && y < p.height;
 
     LaneStack stk;
-    stk.lds = &s_stack[threadIdx.x];
+    stk.lds = &s_stack[MODE > 0 ? threadIdx.x : 0];
     LaneStats st;
+    float ox, oy;
+    sample_offset(p.grid, s, &ox, &oy);
+    // src/main.rs:314,322-330. aspect_ratio is an integer division in the reference.
+    const float aspect = (float)(p.width / p.height);
+    const float xx = (2.0f * ((float)x + ox) / (float)p.width - 1.0f) * aspect * 1.0f;
+    const float yy = (1.0f - 2.0f * ((float)y + oy) / (float)p.height) * 1.0f;
+    const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(xx, yy, 1.0f);
+    const uint64_t pix = (uint64_t)y * p.width + x;
+    const uint64_t sample_index = pix * spp + s;
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+
+    // depth 1: nearest hit and direct light, src/main.rs:93-241.
+    const HitD h = closest_all_packet<STATS>(sv, o, d, inside, st);
+    const bool hit_any = inside && h.tri != RT_MISS;
+    HitD hs = h;
+    if (!hit_any) hs.tri = 0, hs.obj = 0;  // keep the loads below in range for idle lanes
+    const Surface sf = surface_of(sv, hs, o, d);
+    const rt_f3 sun_dir = g_normalize(sun - sf.pos);
+    const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
+    const bool occluded = any_all_packet<STATS>(sv, sf.pos, sun_dir, lit, st);
     Col color{0.0f, 0.0f, 0.0f};
-    if (inside) {
-        float ox, oy;
-        sample_offset(p.grid, s, &ox, &oy);
-        // src/main.rs:314,322-330. aspect_ratio is an integer division in the reference.
-        const float aspect = (float)(p.width / p.height);
-        const float xx = (2.0f * ((float)x + ox) / (float)p.width - 1.0f) * aspect * 1.0f;
-        const float yy = (1.0f - 2.0f * ((float)y + oy) / (float)p.height) * 1.0f;
-        const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(xx, yy, 1.0f);
-        const uint64_t pix = (uint64_t)y * p.width + x;
-        const uint64_t sample_index = pix * spp + s;
-        uint32_t primary = RT_MISS;
-        bool hit_any;
-        if (!BOUNCES || p.diffuse_depth <= 1) {
-            color = mirror_chain<STATS>(sv, p, o, d, 1, &primary, stk, st);
-            hit_any = primary != RT_MISS;
-        } else {
-            // depth 1 with diffuse scattering, src/main.rs:173-301.
-            const HitD h = closest_all<STATS>(sv, o, d, stk, st);
-            primary = h.tri;
-            hit_any = h.tri != RT_MISS;
-            if (!hit_any) {
-                color = sky();
-            } else {
-                const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-                const Surface sf = surface_of(sv, h, o, d);
-                color = direct_light<STATS>(sv, sf, sun, stk, st);
-                Col reflect_color{0.0f, 0.0f, 0.0f};
-                if (1u < p.reflect_depth && sf.reflectivity > 0.0f) {
-                    const rt_f3 rd = d - 2.0f * sf.normal * g_dot(d, sf.normal);
-                    reflect_color = cmul(mirror_chain<STATS>(sv, p, sf.pos, rd, 2, nullptr, stk, st), sf.reflectivity);
-                }
-                Col diffuse_color{0.0f, 0.0f, 0.0f};
-                rt_f3 tang1, tang2;
-                tangent_vectors(sf.normal, &tang1, &tang2);
-                for (uint32_t k = 0; k < p.diffuse_scatt; ++k) {
-                    const float sin_theta = __builtin_sqrtf(counter_rand(p.seed, sample_index, k, 0));
-                    const float cos_theta = __builtin_sqrtf(1.0f - sin_theta * sin_theta);
-                    const float psi = counter_rand(p.seed, sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
-                    const float a = sin_theta * cosf(psi);
-                    const float b = sin_theta * sinf(psi);
-                    const float c = cos_theta;
-                    const rt_f3 vel = g_normalize(f3(a * tang1.x + b * tang2.x + c * sf.normal.x,
-                                                     a * tang1.y + b * tang2.y + c * sf.normal.y,
-                                                     a * tang1.z + b * tang2.z + c * sf.normal.z));
-                    const float light_power = g_dot(sf.normal, vel);
-                    const Col col = mirror_chain<STATS>(sv, p, sf.pos, vel, 2, nullptr, stk, st);
-                    diffuse_color = cadd(diffuse_color, cmul(cmul_col(col, sf.color), light_power * sf.roughness));
-                }
-                diffuse_color = cdiv(diffuse_color, (float)p.diffuse_scatt);
-                color = cadd(color, reflect_color);
-                color = cadd(color, diffuse_color);
-            }
+    if (lit && !occluded) color = cmul(sf.color, g_dot(sf.normal, sun_dir) * sf.albedo);
+
+    if (MODE >= 1 && hit_any) {
+        Col reflect_color{0.0f, 0.0f, 0.0f};
+        if (1u < p.reflect_depth && sf.reflectivity > 0.0f) {
+            const rt_f3 rd = d - 2.0f * sf.normal * g_dot(d, sf.normal);
+            reflect_color = cmul(mirror_chain<STATS>(sv, p, sf.pos, rd, 2, stk, st), sf.reflectivity);
         }
-        // Gamma only for samples that hit something, src/main.rs:302-310.
-        if (hit_any) color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
-        if (hit_ids) hit_ids[sample_index] = primary;
+        Col diffuse_color{0.0f, 0.0f, 0.0f};
+        if (MODE >= 2 && 1u < p.diffuse_depth) {
+            rt_f3 tang1, tang2;
+            tangent_vectors(sf.normal, &tang1, &tang2);
+            for (uint32_t k = 0; k < p.diffuse_scatt; ++k) {
+                const float sin_theta = __builtin_sqrtf(counter_rand(p.seed, sample_index, k, 0));
+                const float cos_theta = __builtin_sqrtf(1.0f - sin_theta * sin_theta);
+                const float psi = counter_rand(p.seed, sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
+                const float a = sin_theta * cosf(psi);
+                const float b = sin_theta * sinf(psi);
+                const float c = cos_theta;
+                const rt_f3 vel = g_normalize(f3(a * tang1.x + b * tang2.x + c * sf.normal.x,
+                                                 a * tang1.y + b * tang2.y + c * sf.normal.y,
+                                                 a * tang1.z + b * tang2.z + c * sf.normal.z));
+                const float light_power = g_dot(sf.normal, vel);
+                const Col col = mirror_chain<STATS>(sv, p, sf.pos, vel, 2, stk, st);
+                diffuse_color = cadd(diffuse_color, cmul(cmul_col(col, sf.color), light_power * sf.roughness));
+            }
+            diffuse_color = cdiv(diffuse_color, (float)p.diffuse_scatt);
+        }
+        color = cadd(color, reflect_color);
+        color = cadd(color, diffuse_color);
     }
+    // Gamma only for samples that hit something; the sky is returned as is, src/main.rs:302-310.
+    if (hit_any) color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+    else color = inside ? sky() : Col{0.0f, 0.0f, 0.0f};
+    if (hit_ids && inside) hit_ids[sample_index] = h.tri;
     if (STATS) flush_stats(st, stats);
 
     // Average the pixel's samples in order (c1 + c2 + c3 + c4) / n, src/main.rs:365.
@@ -697,26 +956,24 @@ hipError_t gather_records(const float* d_tri9, const uint32_t* d_order, uint32_t
     return hipGetLastError();
 }
 
-hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, bool bounces,
+hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, int mode,
                   uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats, hipStream_t s) {
     const uint32_t ppb = RT_BLOCK / p.spp;
     const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / ppb);
     if (blocks == 0) return hipSuccess;
+#define RT_LAUNCH(M, S)                                                                                          \
+    hipLaunchKernelGGL((k_render<M, S>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_rgba8, d_hit_ids, \
+                       d_stats)
     if (d_stats) {
-        if (bounces)
-            hipLaunchKernelGGL((k_render<true, true>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_rgba8,
-                               d_hit_ids, d_stats);
-        else
-            hipLaunchKernelGGL((k_render<false, true>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list,
-                               d_rgba8, d_hit_ids, d_stats);
+        if (mode == 0) RT_LAUNCH(0, true);
+        else if (mode == 1) RT_LAUNCH(1, true);
+        else RT_LAUNCH(2, true);
     } else {
-        if (bounces)
-            hipLaunchKernelGGL((k_render<true, false>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list,
-                               d_rgba8, d_hit_ids, d_stats);
-        else
-            hipLaunchKernelGGL((k_render<false, false>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list,
-                               d_rgba8, d_hit_ids, d_stats);
+        if (mode == 0) RT_LAUNCH(0, false);
+        else if (mode == 1) RT_LAUNCH(1, false);
+        else RT_LAUNCH(2, false);
     }
+#undef RT_LAUNCH
     return hipGetLastError();
 }
 
