@@ -216,3 +216,98 @@ def test_render_sharded_tiles_cover_the_frame(teapot_pair):
         assert not (acc.astype(bool) & part.astype(bool))[..., 3].any(), "two shards wrote one pixel"
         acc |= part
     assert np.array_equal(acc, full)
+
+
+@pytest.mark.parametrize("name", ["teapot", "soup4k"])
+def test_golden_vectors(name, ctx, default_objects):
+    """The committed vectors (tests/golden/vectors.npz, written by tests/golden/make_golden.py from
+    the oracle): ids and t, u, v bit for bit; frames within 1 LSB."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "vectors.npz"))
+    objs = default_objects if name == "teapot" else scenes.soup(4096, 0x5EED0001)
+    g = Scene(ctx, objs)
+    rays = gold[f"{name}_rays"]
+    h = g.trace_closest(rays)
+    assert np.array_equal(h["tri"], gold[f"{name}_tri"])
+    hit = h["tri"] != RT_MISS
+    tuv = np.stack([h["t"], h["u"], h["v"]], axis=1).view(np.uint32)
+    assert np.array_equal(tuv[hit], gold[f"{name}_tuv"][hit])
+    assert np.array_equal(g.trace_any(rays), gold[f"{name}_occluded"])
+    rgba, ids = g.render(render_params(64, 36, 2, reflect_depth=1, diffuse_depth=1), want_hit_ids=True)
+    assert np.array_equal(ids, gold[f"{name}_frame_direct_ids"])
+    assert np.abs(rgba.astype(np.int16) - gold[f"{name}_frame_direct"].astype(np.int16)).max() <= 1
+    rgba = g.render(render_params(64, 36, 2, seed=99))
+    d = np.abs(rgba.astype(np.int16) - gold[f"{name}_frame_full"].astype(np.int16))
+    assert (d > 1).mean() <= 1e-3
+
+
+def test_deinterleave_kernel_matches_numpy(ctx):
+    import torch
+
+    from raytracing_amd import distributed as rd
+
+    w, h, n = 200, 120, 3
+    slab = rd.slab_tiles(w, h, n)
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 256, size=(n, slab, 32, 32, 4), dtype=np.uint8)
+    dg = torch.from_numpy(g).cuda()
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    ctx.deinterleave_device(dg.data_ptr(), slab, w, h, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), rd.deinterleave_numpy(g, w, h, n))
+
+
+def test_device_entry_points_match_host_entry_points(teapot_pair):
+    """rt_trace_*_device and rt_render_device on torch-owned device memory."""
+    import torch
+
+    from raytracing_amd import HIT_DTYPE
+
+    g, _ = teapot_pair
+    rays = scenes.camera_rays(160, 90, 2)
+    ref = g.trace_closest(rays)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_out = torch.zeros(len(rays) * 4, dtype=torch.int32, device="cuda")
+    d_occ = torch.zeros(len(rays), dtype=torch.uint8, device="cuda")
+    sh = torch.cuda.current_stream().cuda_stream
+    g.trace_closest_device(d_rays.data_ptr(), len(rays), d_out.data_ptr(), sh)
+    g.trace_any_device(d_rays.data_ptr(), len(rays), d_occ.data_ptr(), sh)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(HIT_DTYPE)
+    assert np.array_equal(got["tri"], ref["tri"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(d_occ.cpu().numpy(), g.trace_any(rays))
+    p = render_params(160, 90, 2, reflect_depth=1, diffuse_depth=1)
+    frame = torch.zeros((90, 160, 4), dtype=torch.uint8, device="cuda")
+    g.render_device(p, frame.data_ptr(), None, sh)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), g.render(p))
+    st = g.render_device_stats(p, frame.data_ptr())
+    assert st["rays"] >= 160 * 90 * 4 and st["tri_tests"] > 0 and st["box_tests"] > 0
+
+
+def test_full_size_properties_soup_1m(ctx, oracle):
+    """BASELINE configuration 3 at full size: 1,000,000 triangles, 3840x2160, four samples. The
+    oracle cannot scan it in full in test time, so: a strided subsample is compared ray by ray, the
+    frame is deterministic across runs, and the hit-id buffer is consistent with the frame."""
+    objs = scenes.soup(1_000_000, 0x5EED0001)
+    g = Scene(ctx, objs)
+    W, H = 3840, 2160
+    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1)
+    rgba, ids = g.render(p, want_hit_ids=True)
+    rgba2 = g.render(p)
+    assert np.array_equal(rgba, rgba2), "frame is not deterministic"
+    assert (rgba[..., 3] == 255).all()
+    hit = ids != RT_MISS
+    assert 0.5 < hit.mean() < 1.0 and ids[hit].max() < 1_000_000
+    # pixels whose four samples all miss are exactly the sky colour
+    sky = ~hit.reshape(-1, 4).any(axis=1)
+    assert sky.any() and (rgba.reshape(-1, 4)[sky] == np.array([0x87, 0xCE, 0xEB, 0xFF], dtype=np.uint8)).all()
+    # strided subsample against the oracle (every 4099th pixel: 2,023 pixels, 8,092 rays)
+    pix = np.arange(0, W * H, 4099)
+    rays = scenes.camera_rays(W, H, 2, pixels=pix)
+    ref = oracle.OracleScene(objs).trace_closest(rays)
+    sub = ids.reshape(-1, 4)[pix].reshape(-1)
+    assert (sub != ref["tri"]).mean() <= 1e-3
+    batch = g.trace_closest(rays)
+    _compare_hits(batch, ref, 1e-3)
