@@ -122,25 +122,38 @@ def main():
         dist.all_reduce(counts)
     rays_total, box_total, tri_total = [int(x) for x in counts.tolist()]
 
-    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    k_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # Raw HIP events around the frame's phases, recorded by the library on the stream it launches
+    # on: [0] start, [1] camera-ray kernel done, [2] sort done, [3] shadow kernel done, [4] resolve done.
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def new_event():
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        return e
+
+    def elapsed_ms(a, b):
+        ms = ctypes.c_float()
+        assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+        return ms.value
+
+    phase_events = [[new_event() for _ in range(5)] for _ in range(args.steps)]
 
     def step(i, timed_index=None):
         b = i % 2
         if world == 1:
             if timed_index is not None:
-                k_start[timed_index].record(stream)
-            scene.render_device(p, frames[0].data_ptr(), None, sh)
-            if timed_index is not None:
-                k_end[timed_index].record(stream)
+                scene.render_device_events(p, frames[0].data_ptr(), [e.value for e in phase_events[timed_index]], None, sh)
+            else:
+                scene.render_device(p, frames[0].data_ptr(), None, sh)
             return
         # The buffer must not be overwritten before its previous gather has read it.
         stream.wait_event(gather_done[b])
         if timed_index is not None:
-            k_start[timed_index].record(stream)
-        scene.render_device(p, frames[b].data_ptr(), None, sh)
-        if timed_index is not None:
-            k_end[timed_index].record(stream)
+            scene.render_device_events(p, frames[b].data_ptr(), [e.value for e in phase_events[timed_index]], None, sh)
+        else:
+            scene.render_device(p, frames[b].data_ptr(), None, sh)
         render_done[b].record(stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
@@ -169,16 +182,20 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(k_start, k_end)]))
+    phase_ms = [float(np.mean([elapsed_ms(ev[k], ev[k + 1]) for ev in phase_events])) for k in range(4)]
+    kernel_ms = phase_ms[0]  # the camera-ray kernel, the longest of the frame
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total * args.steps / elapsed / 1e6
         # Roofline of the frame kernel on this rank (per launch): algorithmic bytes = frame bytes
         # written + structure bytes of the slab and triangle tests the launch performs.
-        my_box, my_tri = st["box_tests"], st["tri_tests"]
-        frame_bytes = (W * H * 4) // world
-        alg_bytes = frame_bytes + BYTES_BOX * my_box + BYTES_TRI * my_tri
+        # Dominant kernel = the camera-ray kernel (k_wf_primary). Per launch it writes 28 B per sample
+        # (hit point + id 16 B, state 4 B, sort key 4 B, sort value 4 B); camera rays are generated on
+        # the device (0 B in); structure bytes follow its own slab / triangle test counters.
+        my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
+        n_samples_rank = st["primary_rays"]
+        alg_bytes = 28 * n_samples_rank + BYTES_BOX * my_box + BYTES_TRI * my_tri
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
         out = {
@@ -200,12 +217,14 @@ def main():
                 "rays_per_frame": rays_total,
                 "box_tests_per_ray": box_total / max(1, rays_total),
                 "tri_tests_per_ray": tri_total / max(1, rays_total),
+                "phase_ms": {"camera_rays": phase_ms[0], "shadow_sort": phase_ms[1], "shadow_rays": phase_ms[2],
+                             "resolve": phase_ms[3]},
                 "scene_build_s": build_s,
                 "parallelism": f"tiles{world}" if world > 1 else "single",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_render",
+                "kernel": "k_wf_primary",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",

@@ -79,13 +79,19 @@ typedef struct {
     uint32_t shard_count;     /* 1 = render the whole frame                                  */
 } rt_render_params;
 
-/* Counters of one rt_render*_stats call. */
+/* Counters of one rt_render_device_stats call: whole frame, then the camera-ray kernel alone
+ * (equal to the whole frame when the frame runs as one kernel). */
 typedef struct {
     uint64_t rays;        /* nearest-hit + any-hit searches                                  */
-    uint64_t box_tests;   /* ray / AABB slab tests                                           */
+    uint64_t box_tests;   /* ray / AABB tests (per ray, or per wave where a wave tests a box
+                             once for all its rays)                                          */
     uint64_t tri_tests;   /* ray / triangle tests                                            */
     uint64_t node_visits; /* inner-node fetches                                              */
+    uint64_t primary_rays, primary_box_tests, primary_tri_tests, primary_node_visits;
 } rt_stats;
+
+/* Number of events rt_render_device_events records. */
+#define RT_RENDER_EVENTS 5
 
 #define RT_TILE 32u   /* screen tiles are RT_TILE x RT_TILE pixels                           */
 
@@ -140,6 +146,12 @@ int  rt_render(rt_scene*, const rt_render_params*, uint8_t* rgba8, uint32_t* hit
  * rt_shard_tiles() tiles, each RT_TILE * RT_TILE * 4 bytes, in ascending tile id. */
 int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                       void* stream);
+/* As rt_render_device, and records the caller's hipEvent_t handles on the stream around the
+ * frame's phases: events[0] before the camera-ray kernel, [1] after it, [2] after the shadow-ray
+ * sort, [3] after the shadow-ray kernel, [4] after the resolve kernel. A frame that runs as one
+ * kernel records [0] before and [1]..[4] after it. For measurement; no reference counterpart. */
+int  rt_render_device_events(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
+                             void* stream, void* const* events, int n_events);
 /* As rt_render_device, from an instrumented build of the same kernels; synchronises and fills
  * *stats. Used for the roofline figures, never for timing. */
 int  rt_render_device_stats(rt_scene*, const rt_render_params*, uint8_t* d_rgba8,

@@ -10,7 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB = os.path.join(LIB_DIR, "librays_hip.so")
+# RAYS_HIP_LIB selects another build of the same library (A/B runs of kernel variants).
+HIP_LIB = os.environ.get("RAYS_HIP_LIB") or os.path.join(LIB_DIR, "librays_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "librays_host.so")
 
 RT_MISS = 0xFFFFFFFF
@@ -57,6 +58,10 @@ class rt_stats(C.Structure):
         ("box_tests", C.c_uint64),
         ("tri_tests", C.c_uint64),
         ("node_visits", C.c_uint64),
+        ("primary_rays", C.c_uint64),
+        ("primary_box_tests", C.c_uint64),
+        ("primary_tri_tests", C.c_uint64),
+        ("primary_node_visits", C.c_uint64),
     ]
 
 
@@ -80,6 +85,7 @@ SYMBOLS = {
     "rt_trace_closest_linear": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
     "rt_render": (C.c_int, [_VP, C.POINTER(rt_render_params), _VP, _VP]),
     "rt_render_device": (C.c_int, [_VP, C.POINTER(rt_render_params), _VP, _VP, _VP]),
+    "rt_render_device_events": (C.c_int, [_VP, C.POINTER(rt_render_params), _VP, _VP, _VP, C.POINTER(_VP), C.c_int]),
     "rt_render_device_stats": (C.c_int, [_VP, C.POINTER(rt_render_params), _VP, _VP, C.POINTER(rt_stats)]),
     "rt_shard_tiles": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_deinterleave_tiles_device": (
@@ -281,7 +287,13 @@ class Scene:
     def render_device_stats(self, params, rgba_ptr, hit_ids_ptr=None):
         st = rt_stats()
         check(self.lib.rt_render_device_stats(self.handle, C.byref(params), rgba_ptr, hit_ids_ptr, C.byref(st)))
-        return {"rays": st.rays, "box_tests": st.box_tests, "tri_tests": st.tri_tests, "node_visits": st.node_visits}
+        return {name: getattr(st, name) for name, _ in rt_stats._fields_}
+
+    def render_device_events(self, params, rgba_ptr, events, hit_ids_ptr=None, stream=0):
+        """events: sequence of RT_RENDER_EVENTS raw hipEvent_t handles (ints)."""
+        arr = (_VP * len(events))(*events)
+        check(self.lib.rt_render_device_events(self.handle, C.byref(params), rgba_ptr, hit_ids_ptr, stream, arr,
+                                               len(events)))
 
 
 def shard_tiles(width, height, shard_index, shard_count):

@@ -213,11 +213,55 @@ struct Collapser {
     const Builder& b;
     Result& out;
     uint32_t node_base, record_base;
+    std::vector<uint32_t> leaf_ref;  // per binary node: the leaf reference once emitted
 
     uint32_t emit_leaf(const Node2& n) {
         const uint32_t first = (uint32_t)out.order.size();
         for (uint32_t i = 0; i < n.count; ++i) out.order.push_back(b.idx_[n.first + i]);
-        return LEAF_BIT | ((record_base + first) << 3) | (n.count - 1);
+        const uint32_t ref = LEAF_BIT | ((record_base + first) << 3) | (n.count - 1);
+        leaf_ref[(size_t)(&n - b.nodes_.data())] = ref;
+        return ref;
+    }
+
+    // Wide collapse of binary inner node `root2`: opens the largest inner child until `width`
+    // children are reached. Returns the node's reference.
+    uint32_t emit_wide(uint32_t root2, uint32_t width, uint32_t wide_base, uint32_t depth) {
+        out.wide_depth = std::max(out.wide_depth, depth);
+        std::vector<uint32_t> kids;
+        kids.push_back(b.nodes_[root2].left);
+        kids.push_back(b.nodes_[root2].right);
+        while (kids.size() < width) {
+            int pick = -1;
+            float best = -1.0f;
+            for (size_t i = 0; i < kids.size(); ++i) {
+                const Node2& c = b.nodes_[kids[i]];
+                if (c.count == 0) {
+                    float a = half_area(c);
+                    if (a > best) {
+                        best = a;
+                        pick = (int)i;
+                    }
+                }
+            }
+            if (pick < 0) break;
+            const Node2& c = b.nodes_[kids[(size_t)pick]];
+            kids[(size_t)pick] = c.left;
+            kids.push_back(c.right);
+        }
+        const uint32_t first = (uint32_t)out.wide.size();
+        out.wide.resize(first + kids.size());
+        for (size_t i = 0; i < kids.size(); ++i) {
+            const Node2& c = b.nodes_[kids[i]];
+            Child ch;
+            for (int k = 0; k < 3; ++k) {
+                ch.lo[k] = c.lo[k];
+                ch.hi[k] = c.hi[k];
+            }
+            ch.pad = 0;
+            ch.ref = c.count > 0 ? leaf_ref[kids[i]] : emit_wide(kids[i], width, wide_base, depth + 1);
+            out.wide[first + i] = ch;
+        }
+        return ((wide_base + first) << 6) | (uint32_t)(kids.size() - 1);
     }
 
     static float half_area(const Node2& n) {
@@ -290,11 +334,15 @@ struct Collapser {
 }  // namespace
 
 void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32_t record_base,
-           int n_threads, bool balanced, Result* out) {
+           uint32_t wide_width, uint32_t wide_base, int n_threads, bool balanced, Result* out) {
     out->nodes.clear();
     out->order.clear();
+    out->wide.clear();
     out->max_stack = 0;
+    out->wide_root = 0;
+    out->wide_depth = 0;
     if (n == 0) return;
+    wide_width = std::min(std::max(wide_width, 2u), MAX_WIDE);
     std::vector<Prim> prims(n);
     for (uint32_t i = 0; i < n; ++i) {
         const float* b = tri_bounds + 6 * (size_t)i;
@@ -311,7 +359,7 @@ void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32
     const uint32_t root = b.run();
     out->nodes.reserve(n / 2 + 8);
     out->order.reserve(n);
-    Collapser c{b, *out, node_index_base, record_base};
+    Collapser c{b, *out, node_index_base, record_base, std::vector<uint32_t>(b.nodes_.size(), EMPTY)};
     const Node2& r = b.nodes_[root];
     if (r.count > 0) {
         // A single leaf: wrap it in a one-child inner node so that the root is always inner.
@@ -331,9 +379,14 @@ void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32
         out->nodes.push_back(n4);
         out->nodes[0].c[0].ref = c.emit_leaf(r);
         out->max_stack = 1;
+        Child ch = out->nodes[0].c[0];
+        out->wide.push_back(ch);
+        out->wide_root = (wide_base << 6) | 0u;
+        out->wide_depth = 1;
     } else {
         uint32_t ri;
         out->max_stack = c.emit_inner(root, &ri) + 1;
+        out->wide_root = c.emit_wide(root, wide_width, wide_base, 1);
     }
 }
 

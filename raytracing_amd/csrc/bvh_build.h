@@ -30,10 +30,19 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr uint32_t MAX_LEAF = 4;
 
+// The same tree collapsed further, for the beam walk in which one lane looks at one child: a
+// node is a run of up to `width` (<= 64) consecutive Child entries. An inner reference is
+// (index of the first child << 6) | (count - 1); leaf references are those of the 4-wide tree
+// and point at the same triangle records.
+constexpr uint32_t MAX_WIDE = 64;
+
 struct Result {
     std::vector<Node4> nodes;     // nodes[0] is the root (always an inner node)
     std::vector<uint32_t> order;  // triangle record r holds input triangle order[r]
     uint32_t max_stack = 0;       // upper bound on pending entries during any traversal
+    std::vector<Child> wide;      // children of the wide nodes
+    uint32_t wide_root = 0;       // reference of the wide root node
+    uint32_t wide_depth = 0;      // number of inner levels on the longest root-to-leaf path
 };
 
 // tri_bounds: n boxes of 6 floats (min xyz, max xyz), exact bounds of each triangle's three
@@ -43,8 +52,9 @@ struct Result {
 // record_base likewise to every leaf's first triangle record.
 // balanced = false: binned surface-area-heuristic splits. balanced = true: median splits only,
 // which bounds the tree depth (and with it max_stack) at the cost of looser boxes.
+// wide_width (2..64) is the fan-out of the wide collapse; wide_base is added to its child indices.
 void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32_t record_base,
-           int n_threads, bool balanced, Result* out);
+           uint32_t wide_width, uint32_t wide_base, int n_threads, bool balanced, Result* out);
 
 }  // namespace rtbvh
 

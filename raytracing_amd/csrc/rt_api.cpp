@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -93,17 +94,37 @@ struct rt_ctx {
     }
 };
 
+// Per-sample buffers of the camera + shadow pipeline, grown on demand and kept with the scene.
+struct FrameWork {
+    size_t capacity = 0;  // sample slots
+    float4* samp = nullptr;
+    uint32_t* state = nullptr;
+    uint32_t* keys[2] = {nullptr, nullptr};
+    uint32_t* vals[2] = {nullptr, nullptr};
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    void release() {
+        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)vals[0], (void*)vals[1], temp})
+            if (q) (void)hipFree(q);
+        *this = FrameWork();
+    }
+};
+
 struct rt_scene {
     rt_ctx* ctx = nullptr;
+    FrameWork work;
+    float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
     SceneView view{};
     std::vector<void*> device_ptrs;
     uint32_t n_tris = 0;
     uint32_t n_leaves = 0;
     uint32_t n_nodes = 0;
     uint32_t max_stack = 0;
+    uint32_t wide_depth = 1;
     std::vector<DevObject> objects;
     std::vector<std::vector<uint32_t>> order;  // per object: sorted position -> input position
     ~rt_scene() {
+        work.release();
         for (void* p : device_ptrs) (void)hipFree(p);
     }
 };
@@ -155,8 +176,13 @@ int check_render_params(const rt_render_params* p, uint32_t* spp) {
     return RT_OK;
 }
 
+// events: null, or RT_RENDER_EVENTS hipEvent_t handles recorded around the phases.
+// primary_stats: null, or receives the counters as they stand after the camera-ray kernel.
 int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
-                  hipStream_t stream) {
+                  hipStream_t stream, void* const* events = nullptr, DevStats* primary_stats = nullptr) {
+    auto mark = [&](int k) -> hipError_t {
+        return events ? hipEventRecord((hipEvent_t)events[k], stream) : hipSuccess;
+    };
     uint32_t spp = 0;
     int rc = check_render_params(p, &spp);
     if (rc != RT_OK) return rc;
@@ -174,6 +200,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     dp.sun[2] = p->sun[2];
     dp.seed = p->seed;
     dp.tiles_x = ceil_div(p->width, RT_TILE);
+    dp.beam_levels = s->wide_depth;
     const uint32_t* d_list = nullptr;
     if (p->shard_count > 1) {
         TileMap* tm = nullptr;
@@ -189,7 +216,83 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     bool reflective = false;
     for (const DevObject& ob : s->objects) reflective = reflective || ob.reflectivity > 0.0f;
     const int mode = p->diffuse_depth > 1 ? 2 : ((reflective && p->reflect_depth > 1) ? 1 : 0);
-    HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
+    if (mode != 0 || std::getenv("RAYS_HIP_MEGAKERNEL")) {
+        HIP_TRY(mark(0));
+        HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
+        for (int k = 1; k < RT_RENDER_EVENTS; ++k) HIP_TRY(mark(k));
+        if (primary_stats && d_stats) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
+        }
+        return RT_OK;
+    }
+    // Camera + shadow rays only: primary kernel, light-space sort of the shadow rays, shadow
+    // kernel, resolve kernel.
+    const size_t n_slots = (size_t)dp.n_tiles * RT_TILE * RT_TILE * spp;
+    if (n_slots == 0) return RT_OK;
+    if (n_slots >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "frame has too many samples");
+    FrameWork& w = s->work;
+    if (w.capacity < n_slots) {
+        w.release();
+        size_t tb = 0;
+        HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n_slots, stream));
+        HIP_TRY(hipMalloc((void**)&w.samp, n_slots * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&w.state, n_slots * 4));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipMalloc((void**)&w.keys[k], n_slots * 4));
+            HIP_TRY(hipMalloc((void**)&w.vals[k], n_slots * 4));
+        }
+        HIP_TRY(hipMalloc(&w.temp, std::max<size_t>(tb, 16)));
+        w.temp_bytes = tb;
+        w.capacity = n_slots;
+    }
+    // Projection from the sun across its dominant axis, scaled to the scene's bounds.
+    LightProj lp{};
+    {
+        float c[3], dsun[3];
+        for (int k = 0; k < 3; ++k) {
+            c[k] = 0.5f * (s->bounds_lo[k] + s->bounds_hi[k]);
+            dsun[k] = std::fabs(c[k] - p->sun[k]);
+        }
+        lp.w = (dsun[0] >= dsun[1] && dsun[0] >= dsun[2]) ? 0 : (dsun[1] >= dsun[2] ? 1 : 2);
+        lp.a1 = lp.w == 0 ? 1 : 0;
+        lp.a2 = lp.w == 2 ? 1 : 2;
+        lp.sun_w = p->sun[lp.w];
+        lp.sun_a1 = p->sun[lp.a1];
+        lp.sun_a2 = p->sun[lp.a2];
+        float u0 = INFINITY, u1 = -INFINITY, v0 = INFINITY, v1 = -INFINITY;
+        bool ok = true;
+        for (int corner = 0; corner < 8; ++corner) {
+            float q[3];
+            for (int k = 0; k < 3; ++k) q[k] = (corner >> k) & 1 ? s->bounds_hi[k] : s->bounds_lo[k];
+            const float pw = q[lp.w] - lp.sun_w;
+            if (!(std::fabs(pw) > 0.0f)) ok = false;
+            const float u = (q[lp.a1] - lp.sun_a1) / pw, v = (q[lp.a2] - lp.sun_a2) / pw;
+            u0 = std::min(u0, u); u1 = std::max(u1, u);
+            v0 = std::min(v0, v); v1 = std::max(v1, v);
+        }
+        // The sun inside the scene's extent along w would make the projection change sign.
+        ok = ok && ((s->bounds_lo[lp.w] - lp.sun_w) * (s->bounds_hi[lp.w] - lp.sun_w) > 0.0f);
+        ok = ok && std::isfinite(u0) && std::isfinite(u1) && std::isfinite(v0) && std::isfinite(v1);
+        lp.u0 = ok ? u0 : 0.0f;
+        lp.v0 = ok ? v0 : 0.0f;
+        lp.uscale = (ok && u1 > u0) ? 65535.0f / (u1 - u0) : 0.0f;  // 0: every ray gets the same key
+        lp.vscale = (ok && v1 > v0) ? 65535.0f / (v1 - v0) : 0.0f;
+    }
+    HIP_TRY(mark(0));
+    HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], w.vals[0], d_stats, stream));
+    HIP_TRY(mark(1));
+    if (primary_stats && d_stats) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
+    }
+    size_t tb = w.temp_bytes;
+    HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], w.vals[0], w.vals[1], n_slots, stream));
+    HIP_TRY(mark(2));
+    HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, w.keys[1], w.vals[1], w.samp, w.state, d_stats, stream));
+    HIP_TRY(mark(3));
+    HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
+    HIP_TRY(mark(4));
     return RT_OK;
 }
 
@@ -303,16 +406,17 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         }
         ob.tri_base = tri_base;
         ob.n_tris = d.n_tris;
-        ob.n_packed = (d.n_tris / 8) * 8;
-        ob.n_rest = d.n_tris - ob.n_packed;
+        const uint32_t n_packed = (d.n_tris / 8) * 8;
+        ob.wide_root = 0;
+        ob.n_rest = d.n_tris - n_packed;
         ob.rest_base = (uint32_t)(rest_verts.size() / 9);
         ob.leaf_base = (uint32_t)leaf_first.size();
         ob.albedo = d.albedo_over_pi;
         ob.reflectivity = d.reflectivity;
         ob.roughness = d.roughness;
         ob.root = rtbvh::EMPTY;
-        for (uint32_t l = 0; l < ob.n_packed / 8; ++l) leaf_first.push_back(tri_base + l * 8);
-        for (uint32_t i = ob.n_packed; i < d.n_tris; ++i)
+        for (uint32_t l = 0; l < n_packed / 8; ++l) leaf_first.push_back(tri_base + l * 8);
+        for (uint32_t i = n_packed; i < d.n_tris; ++i)
             for (int k = 0; k < 3; ++k) {
                 const float* v = &verts_all[3 * (size_t)tris_all[3 * (size_t)(tri_base + i) + k]];
                 rest_verts.insert(rest_verts.end(), v, v + 3);
@@ -324,13 +428,17 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
 
     // ---- trees: one per object, over its 8-wide triangles ----------------------------------
     std::vector<rtbvh::Node4> nodes_all;
+    std::vector<rtbvh::Child> wide_all;
     std::vector<uint32_t> order_all;  // record -> global triangle id
     const int nt = host_threads();
+    uint32_t wide_width = 32;
+    if (const char* e = std::getenv("RAYS_HIP_WIDE")) wide_width = (uint32_t)std::atoi(e);
     for (uint32_t o = 0; o < n_objs; ++o) {
         DevObject& ob = s->objects[o];
-        if (ob.n_packed == 0) continue;
-        bounds.resize((size_t)ob.n_packed * 6);
-        for (uint32_t i = 0; i < ob.n_packed; ++i) {
+        const uint32_t n_packed = (ob.n_tris / 8) * 8;
+        if (n_packed == 0) continue;
+        bounds.resize((size_t)n_packed * 6);
+        for (uint32_t i = 0; i < n_packed; ++i) {
             const uint32_t* t = &tris_all[3 * (size_t)(ob.tri_base + i)];
             const float *a = &verts_all[3 * (size_t)t[0]], *b = &verts_all[3 * (size_t)t[1]],
                         *c = &verts_all[3 * (size_t)t[2]];
@@ -341,17 +449,39 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         }
         rtbvh::Result res;
         const uint32_t node_base = (uint32_t)nodes_all.size(), rec_base = (uint32_t)order_all.size();
-        rtbvh::build(bounds.data(), ob.n_packed, node_base, rec_base, nt, false, &res);
-        if (res.max_stack > RT_STACK_MAX) rtbvh::build(bounds.data(), ob.n_packed, node_base, rec_base, nt, true, &res);
-        if (res.max_stack > RT_STACK_MAX)
-            return fail(RT_ERR_UNSUPPORTED, "object %u: tree needs %u pending entries, limit %d", o, res.max_stack,
-                        RT_STACK_MAX);
+        const uint32_t wide_base = (uint32_t)wide_all.size();
+        rtbvh::build(bounds.data(), n_packed, node_base, rec_base, wide_width, wide_base, nt, false, &res);
+        if (res.max_stack > RT_STACK_MAX || res.wide_depth > RT_BEAM_LEVELS)
+            rtbvh::build(bounds.data(), n_packed, node_base, rec_base, wide_width, wide_base, nt, true, &res);
+        if (res.max_stack > RT_STACK_MAX || res.wide_depth > RT_BEAM_LEVELS)
+            return fail(RT_ERR_UNSUPPORTED, "object %u: tree too deep (%u pending entries, %u wide levels)", o,
+                        res.max_stack, res.wide_depth);
+        if (wide_all.size() + res.wide.size() >= (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+        ob.wide_root = res.wide_root;
+        wide_all.insert(wide_all.end(), res.wide.begin(), res.wide.end());
         s->max_stack = std::max(s->max_stack, res.max_stack);
+        s->wide_depth = std::max(s->wide_depth, res.wide_depth);
         ob.root = node_base;
         nodes_all.insert(nodes_all.end(), res.nodes.begin(), res.nodes.end());
         for (uint32_t r : res.order) order_all.push_back(ob.tri_base + r);
     }
     s->n_nodes = (uint32_t)nodes_all.size();
+    {
+        bool any_tree = false;
+        for (const DevObject& ob : s->objects) any_tree = any_tree || ob.root != rtbvh::EMPTY;
+        bool first = true;
+        for (const DevObject& ob : s->objects) {
+            if (any_tree && ob.root == rtbvh::EMPTY) continue;
+            for (int k = 0; k < 3; ++k) {
+                s->bounds_lo[k] = first ? ob.bbmin[k] : std::min(s->bounds_lo[k], ob.bbmin[k]);
+                s->bounds_hi[k] = first ? ob.bbmax[k] : std::max(s->bounds_hi[k], ob.bbmax[k]);
+            }
+            first = false;
+        }
+    }
+    if (std::getenv("RAYS_HIP_VERBOSE"))
+        std::fprintf(stderr, "[rays_hip] %u tris, %zu nodes4 (stack bound %u), wide width %u: %zu children, depth %u\n",
+                     s->n_tris, nodes_all.size(), s->max_stack, wide_width, wide_all.size(), s->wide_depth);
 
     // ---- upload and pack on the device -----------------------------------------------------
     DevPool pool;
@@ -359,6 +489,7 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
     uint32_t *d_tris, *d_leaf_first, *d_order;
     float4* d_recs;
     rtbvh::Node4* d_nodes;
+    rtbvh::Child* d_wide;
     DevObject* d_objs;
     DevPool tmp;  // freed on return
     HIP_TRY(tmp.alloc((void**)&d_verts, verts_all.size() * 4));
@@ -371,6 +502,7 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
     HIP_TRY(pool.alloc((void**)&d_rest, rest_verts.size() * 4));
     HIP_TRY(pool.alloc((void**)&d_recs, order_all.size() * 48));
     HIP_TRY(pool.alloc((void**)&d_nodes, nodes_all.size() * sizeof(rtbvh::Node4)));
+    HIP_TRY(pool.alloc((void**)&d_wide, wide_all.size() * sizeof(rtbvh::Child)));
     HIP_TRY(pool.alloc((void**)&d_objs, s->objects.size() * sizeof(DevObject)));
     HIP_TRY(hipMemcpy(d_verts, verts_all.data(), verts_all.size() * 4, hipMemcpyHostToDevice));
     if (!tris_all.empty()) HIP_TRY(hipMemcpy(d_tris, tris_all.data(), tris_all.size() * 4, hipMemcpyHostToDevice));
@@ -383,6 +515,8 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         HIP_TRY(hipMemcpy(d_rest, rest_verts.data(), rest_verts.size() * 4, hipMemcpyHostToDevice));
     if (!nodes_all.empty())
         HIP_TRY(hipMemcpy(d_nodes, nodes_all.data(), nodes_all.size() * sizeof(rtbvh::Node4), hipMemcpyHostToDevice));
+    if (!wide_all.empty())
+        HIP_TRY(hipMemcpy(d_wide, wide_all.data(), wide_all.size() * sizeof(rtbvh::Child), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_objs, s->objects.data(), s->objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
     HIP_TRY(rtk::pack_tris(d_verts, d_tris, (uint32_t)total_tris, d_tri9, 0));
     HIP_TRY(rtk::leaf_bounds(d_verts, d_tris, d_leaf_first, (uint32_t)leaf_first.size(), d_leaf_bounds, 0));
@@ -391,7 +525,15 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
 
     s->view.objs = d_objs;
     s->view.n_objs = n_objs;
+    {
+        float ext = 0.0f;
+        for (int k = 0; k < 3; ++k) ext = std::max(ext, s->bounds_hi[k] - s->bounds_lo[k]);
+        s->view.scene_extent = ext;
+        s->view.beam_limit = ext / 128.0f;
+        if (const char* e = std::getenv("RAYS_HIP_BEAM_DIV")) s->view.beam_limit = ext / (float)std::atof(e);
+    }
     s->view.nodes = d_nodes;
+    s->view.wide = d_wide;
     s->view.recs = d_recs;
     s->view.tri9 = d_tri9;
     s->view.leaf_bounds = d_leaf_bounds;
@@ -426,8 +568,8 @@ int rt_scene_packed(const rt_scene* s, uint32_t obj, float* tris9, float* leaf_b
     const DevObject& ob = s->objects[obj];
     if (tris9 && ob.n_tris)
         HIP_TRY(hipMemcpy(tris9, s->view.tri9 + 9 * (size_t)ob.tri_base, (size_t)ob.n_tris * 36, hipMemcpyDeviceToHost));
-    if (leaf_bounds6 && ob.n_packed)
-        HIP_TRY(hipMemcpy(leaf_bounds6, s->view.leaf_bounds + 6 * (size_t)ob.leaf_base, (size_t)(ob.n_packed / 8) * 24,
+    if (leaf_bounds6 && ob.n_tris >= 8)
+        HIP_TRY(hipMemcpy(leaf_bounds6, s->view.leaf_bounds + 6 * (size_t)ob.leaf_base, (size_t)(ob.n_tris / 8) * 24,
                           hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -510,6 +652,17 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, u
     return render_common(s, p, d_rgba8, d_hit_ids, nullptr, (hipStream_t)stream);
 }
 
+int rt_render_device_events(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, void* stream,
+                            void* const* events, int n_events) {
+    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (!events || n_events != RT_RENDER_EVENTS) return fail(RT_ERR_INVALID, "need %d events", RT_RENDER_EVENTS);
+    for (int k = 0; k < n_events; ++k)
+        if (!events[k]) return fail(RT_ERR_INVALID, "event %d is null", k);
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    return render_common(s, p, d_rgba8, d_hit_ids, nullptr, (hipStream_t)stream, events);
+}
+
 int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                            rt_stats* stats) {
     if (!s || !stats) return fail(RT_ERR_INVALID, "null argument");
@@ -519,7 +672,8 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     DevStats* d_stats;
     HIP_TRY(tmp.alloc((void**)&d_stats, sizeof(DevStats)));
     HIP_TRY(hipMemset(d_stats, 0, sizeof(DevStats)));
-    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0);
+    DevStats hp{};
+    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     DevStats h;
@@ -528,6 +682,10 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     stats->box_tests = h.box_tests;
     stats->tri_tests = h.tri_tests;
     stats->node_visits = h.node_visits;
+    stats->primary_rays = hp.rays;
+    stats->primary_box_tests = hp.box_tests;
+    stats->primary_tri_tests = hp.tri_tests;
+    stats->primary_node_visits = hp.node_visits;
     return RT_OK;
 }
 

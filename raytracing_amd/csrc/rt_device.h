@@ -8,10 +8,12 @@
 #include "bvh_build.h"
 
 #define RT_BLOCK 256        // threads per workgroup: four 64-lane waves
+#define RT_BLOCK0 256       // workgroup of the frame megakernel when it needs no per-lane stacks
 #define RT_STACK_LDS 16     // traversal stack entries kept in LDS per lane
 #define RT_STACK_SPILL 80   // further entries in private memory
 #define RT_STACK_MAX (RT_STACK_LDS + RT_STACK_SPILL)
 #define RT_MAX_REFLECT 8    // deepest mirror chain the frame kernel keeps on its stack
+#define RT_BEAM_LEVELS 16   // wide-tree levels whose pending children a wave keeps in LDS
 
 // One object of the World (src/objects.rs:18-39), as the kernels see it. 64 bytes.
 struct DevObject {
@@ -19,8 +21,8 @@ struct DevObject {
     float bbmax[3];
     uint32_t tri_base;     // global id of the object's first triangle
     uint32_t n_tris;       // all triangles
-    uint32_t n_packed;     // 8 * (n_tris / 8): triangles tested with the 8-wide arithmetic
-    uint32_t root;         // index of the object's root node, EMPTY when n_packed == 0
+    uint32_t wide_root;    // reference of the object's wide root node (beam walk)
+    uint32_t root;         // index of the object's 4-wide root node, EMPTY when n_tris < 8
     uint32_t rest_base;    // first entry in rest_verts of the trailing n_tris % 8 triangles
     uint32_t n_rest;
     float albedo;          // Material (src/objects.rs:176-190); albedo already divided by PI
@@ -34,13 +36,16 @@ static_assert(sizeof(DevObject) == 64, "DevObject layout");
 struct SceneView {
     const DevObject* objs;
     uint32_t n_objs;
-    const rtbvh::Node4* nodes;  // all objects' trees, 128 B per node
+    const rtbvh::Node4* nodes;  // all objects' 4-wide trees, 128 B per node
+    const rtbvh::Child* wide;   // all objects' wide trees, 32 B per child
     const float4* recs;         // triangle records in tree-leaf order, 3 x float4 each:
                                 //   (v0.x v0.y v0.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z id - -)
     const float* tri9;          // reference order: e1 xyz, e2 xyz, v0 xyz per triangle
     const float* leaf_bounds;   // reference order: min xyz, max xyz per 8-triangle leaf
     const float* tri_data;      // reference order: normal xyz, color rgb per triangle
     const float* rest_verts;    // a xyz, b xyz, c xyz of every trailing triangle
+    float beam_limit;           // widest beam footprint worth a beam walk (scene extent / 128)
+    float scene_extent;         // largest side of the bounding box of the objects that have a tree
 };
 
 struct DevRenderParams {
@@ -51,6 +56,14 @@ struct DevRenderParams {
     uint32_t tiles_x;          // tiles per row of the frame
     uint32_t n_tiles;          // tiles this launch renders
     uint32_t compact;          // 1: write tile-compact output, 0: write the frame in place
+    uint32_t beam_levels;      // deepest wide tree of the scene (levels of pending children kept in LDS)
+};
+
+// Projection used to order shadow rays: from the sun onto the plane across its dominant axis w.
+struct LightProj {
+    int w, a1, a2;                 // dominant axis of (scene centre - sun) and the two others
+    float sun_w, sun_a1, sun_a2;   // sun position on those axes
+    float u0, uscale, v0, vscale;  // quantisation of the projected coordinates to 16 bits each
 };
 
 struct DevStats {

@@ -21,6 +21,17 @@ hipError_t gather_records(const float* d_tri9, const uint32_t* d_order, uint32_t
 // mode: 0 camera + shadow rays, 1 + mirror chains, 2 + diffuse scattering (see k_render).
 hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, int mode,
                   uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats, hipStream_t s);
+// Camera + shadow frame as separate kernels around a sort (see rt_kernels.hip).
+hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
+                      float4* d_samp, uint32_t* d_state, uint32_t* d_keys, uint32_t* d_vals, DevStats* d_stats,
+                      hipStream_t s);
+hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, const uint32_t* d_keys,
+                     const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state, DevStats* d_stats, hipStream_t s);
+hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
+                      const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
+// Radix sort of (u32 key, u32 value) pairs. With temp == nullptr only *temp_bytes is set.
+hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s);
 hipError_t deinterleave(const uint8_t* d_gathered, const uint32_t* d_tile_slot, uint32_t slab_tiles, uint32_t width,
                         uint32_t height, uint32_t tiles_x, uint32_t n_tiles_total, uint32_t shard_count,
                         uint8_t* d_rgba8, hipStream_t s);

@@ -391,10 +391,225 @@ __device__ __forceinline__ void packet_search(const SceneView& sv, uint32_t root
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Beam walk: for a wave whose rays all point into the same octant, inner nodes are tested once per
+// wave against the beam that bounds the wave's rays (origin interval and reciprocal-direction
+// interval per axis), with ONE LANE PER CHILD of a wide node instead of one lane per ray. The
+// test is conservative (interval arithmetic plus a relative margin), so the beam reaches every
+// leaf some ray of the wave could reach; at a leaf every lane tests its own ray against the
+// leaf's triangles with the exact arithmetic, as in the other walks.
+// Pending children of each level stay in registers (current level) or LDS (outer levels) as
+// (key, reference) per lane; the nearest pending child is found with a DPP wave-minimum, and a
+// child is dropped without a visit once its entry distance lies beyond every ray's nearest hit.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+// row_shr:1,2,4,8 then row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3): lane 63 ends up with the
+// reduction over the wave.
+#define RT_WAVE_REDUCE(T, OP, FROM_I, TO_I)                       \
+    v = OP(v, FROM_I(dpp_i<0x111, 0xF>(TO_I(v))));                \
+    v = OP(v, FROM_I(dpp_i<0x112, 0xF>(TO_I(v))));                \
+    v = OP(v, FROM_I(dpp_i<0x114, 0xF>(TO_I(v))));                \
+    v = OP(v, FROM_I(dpp_i<0x118, 0xF>(TO_I(v))));                \
+    v = OP(v, FROM_I(dpp_i<0x142, 0xA>(TO_I(v))));                \
+    v = OP(v, FROM_I(dpp_i<0x143, 0xC>(TO_I(v))));                \
+    return FROM_I(__builtin_amdgcn_readlane(TO_I(v), 63));
+__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int id_i(int x) { return x; }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { RT_WAVE_REDUCE(uint32_t, umin_, (uint32_t), (int)) }
+__device__ __forceinline__ float wave_min_f32(float v) { RT_WAVE_REDUCE(float, fminf, __int_as_float, __float_as_int) }
+__device__ __forceinline__ float wave_max_f32(float v) { RT_WAVE_REDUCE(float, fmaxf, __int_as_float, __float_as_int) }
+#undef RT_WAVE_REDUCE
+
+// The beam of a wave, wave-uniform. Rays are written along their dominant axis w (the axis with
+// the largest direction component, mirrored so that every ray travels towards +w): on each of
+// the two lateral axes a, a ray is the line  coord_a = A + B * w  with B = d_a / d_w and
+// A = o_a - B * o_w. The beam keeps the intervals of A and B over the wave's rays. This form is
+// tight both for rays leaving one point (camera rays: A = 0, B spans the pixel footprint) and for
+// parallel rays starting anywhere along a line (sun shadow rays: B is one value and A barely
+// moves, however far apart the origins are in depth).
+struct Beam {
+    int m;            // dominant axis 0..2
+    float sgn;        // +1 or -1: w = sgn * coord_m
+    int ax[2];        // the two lateral axes
+    float a0[2], a1[2], b0[2], b1[2];
+    float amax[2], bmax[2];  // largest magnitudes, for the rounding margin
+    float wbase;      // w of the first origin when the walk started: keys are w - wbase
+    float wstart;     // smallest origin w among the lanes the beam covers
+};
+
+#define RT_MARGIN 9.5367431640625e-7f  // 2^-20
+#define RT_MAX_SLOPE 8.0f
+
+__device__ __forceinline__ float pick3(const rt_f3& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+// Per-lane line coefficients of the beam form.
+struct BeamLane {
+    float ow, dw;  // origin and direction along w (dw > 0)
+};
+
+// Builds the beam of the active lanes. Returns false (wave-uniform) when the rays do not all
+// travel the same way along one common dominant axis, a lateral slope exceeds RT_MAX_SLOPE, or a
+// value is not finite; the caller then uses packet_search. `first` keeps the axis choice and
+// wbase of an earlier build (a refit over fewer lanes).
+__device__ __forceinline__ bool make_beam(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, Beam& b, BeamLane& bl,
+                                          bool first) {
+    const unsigned long long act = __ballot(active);
+    if (act == 0ull) return false;
+    if (first) {
+        const int l0 = __builtin_ctzll(act);
+        const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.x), l0));
+        const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.y), l0));
+        const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.z), l0));
+        const float ax = __builtin_fabsf(dx), ay = __builtin_fabsf(dy), az = __builtin_fabsf(dz);
+        b.m = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        b.sgn = (b.m == 0 ? dx : (b.m == 1 ? dy : dz)) < 0.0f ? -1.0f : 1.0f;
+        b.ax[0] = b.m == 0 ? 1 : 0;
+        b.ax[1] = b.m == 2 ? 1 : 2;
+    }
+    bl.ow = b.sgn * pick3(o, b.m);
+    bl.dw = b.sgn * pick3(d, b.m);
+    bool lane_ok = bl.dw > 0.0f && bl.dw < RT_INF && __builtin_fabsf(bl.ow) < RT_INF;
+    const float rdw = 1.0f / bl.dw;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float oa = pick3(o, b.ax[k]), da = pick3(d, b.ax[k]);
+        const float B = da * rdw;
+        const float A = oa - B * bl.ow;
+        lane_ok = lane_ok && __builtin_fabsf(B) <= RT_MAX_SLOPE && __builtin_fabsf(A) < RT_INF;
+        // rounding of B and of A = oa - B * ow, plus a relative cushion
+        const float eB = __builtin_fabsf(B) * (4.0f * RT_MARGIN);
+        const float eA = (__builtin_fabsf(oa) + __builtin_fabsf(B * bl.ow)) * (4.0f * RT_MARGIN) + 1e-30f;
+        const bool use = active && lane_ok;
+        b.a0[k] = wave_min_f32(use ? A - eA : RT_INF);
+        b.a1[k] = wave_max_f32(use ? A + eA : -RT_INF);
+        b.b0[k] = wave_min_f32(use ? B - eB : RT_INF);
+        b.b1[k] = wave_max_f32(use ? B + eB : -RT_INF);
+        b.amax[k] = fmaxf(__builtin_fabsf(b.a0[k]), __builtin_fabsf(b.a1[k]));
+        b.bmax[k] = fmaxf(__builtin_fabsf(b.b0[k]), __builtin_fabsf(b.b1[k]));
+    }
+    const float ws = wave_min_f32(active ? bl.ow : RT_INF);
+    b.wstart = ws - __builtin_fabsf(ws) * RT_MARGIN;
+    if (first) b.wbase = b.wstart;
+    // A beam much wider than the geometry it meets makes every lane test every triangle of a
+    // large region (rays that happen to share a wave but not a neighbourhood): leave those waves
+    // to the per-ray walk. Footprint = spread of the lines at w = 0 plus their fanning-out
+    // across the scene.
+    bool thin = true;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        thin = thin && ((b.a1[k] - b.a0[k]) + (b.b1[k] - b.b0[k]) * sv.scene_extent) <= sv.beam_limit;
+    return thin && __ballot(active && !lane_ok) == 0ull;
+}
+
+// Tests the children of wide node `ref` (one per lane) against the beam, between the beam's start
+// and wend_rel (the farthest w, relative to wbase, at which any ray can still gain a hit).
+// key = entry w relative to wbase with the lane number in its low six bits (0xFFFFFFFF: no
+// visit), cref = the child's reference.
+template <bool STATS>
+__device__ __forceinline__ void beam_node(const SceneView& sv, uint32_t ref, const Beam& b, float wend_rel,
+                                          uint32_t lane, uint32_t& key, uint32_t& cref, LaneStats& st) {
+    const uint32_t first = ref >> 6, count = (ref & 63u) + 1u;
+    key = 0xFFFFFFFFu;
+    cref = 0;
+    if (STATS && lane == 0) {
+        st.node += 1;
+        st.box += count;
+    }
+    if (lane < count) {
+        const float4* cp = reinterpret_cast<const float4*>(sv.wide + first + lane);
+        const float4 A = cp[0], B = cp[1];  // (lo.x lo.y lo.z hi.x) (hi.y hi.z ref pad)
+        const rt_f3 lo = f3(A.x, A.y, A.z), hi = f3(A.w, B.x, B.y);
+        const float lm = pick3(lo, b.m), hm = pick3(hi, b.m);
+        const float z0 = fmaxf(b.sgn > 0.0f ? lm : -hm, b.wstart);
+        const float z1 = fminf(b.sgn > 0.0f ? hm : -lm, b.wbase + wend_rel);
+        bool hit = z0 <= z1;
+        const float zabs = fmaxf(__builtin_fabsf(z0), __builtin_fabsf(z1));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float p00 = b.b0[k] * z0, p01 = b.b0[k] * z1, p10 = b.b1[k] * z0, p11 = b.b1[k] * z1;
+            const float e = __builtin_fmaf(b.bmax[k], zabs, b.amax[k]) * (4.0f * RT_MARGIN);
+            const float blo = b.a0[k] + fminf(fminf(p00, p01), fminf(p10, p11)) - e;
+            const float bhi = b.a1[k] + fmaxf(fmaxf(p00, p01), fmaxf(p10, p11)) + e;
+            hit = hit && blo <= pick3(hi, b.ax[k]) && bhi >= pick3(lo, b.ax[k]);
+        }
+        if (hit) {
+            key = (__float_as_uint(fmaxf(z0 - b.wbase, 0.0f)) & ~63u) | lane;
+            cref = __float_as_uint(B.z);
+        }
+    }
+}
+
+template <bool ANY, bool STATS>
+__device__ __forceinline__ void beam_search(const SceneView& sv, uint32_t root_ref, uint32_t obj_index, rt_f3 o, rt_f3 d,
+                                            bool active, Beam& b, BeamLane bl, float& closest, HitD& hit,
+                                            bool& occluded, uint2* lds, LaneStats& st) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t local_best = 0;
+    // Farthest useful w per lane, relative to wbase: where the ray's current nearest hit lies.
+    auto far_rel = [&](float c) {
+        const float z = __builtin_fmaf(c, bl.dw, bl.ow);
+        return (z + __builtin_fabsf(z) * (4.0f * RT_MARGIN)) - b.wbase;
+    };
+    float zc = ANY ? RT_INF : far_rel(closest);
+    float wend_rel = ANY ? RT_INF : wave_max_f32(active ? zc : -RT_INF);
+    int n_beam = __builtin_popcountll(__ballot(active));  // lanes the current beam was built from
+    int level = 0;
+    uint32_t key, cref;
+    beam_node<STATS>(sv, root_ref, b, wend_rel, lane, key, cref, st);
+    for (;;) {
+        const uint32_t kmin = wave_min_u32(key);
+        const float kf = __uint_as_float(kmin & ~63u);
+        // Lanes that can still gain from pending children: all unoccluded lanes in shadow mode;
+        // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
+        // walk is front to back along w, so the others are finished).
+        const unsigned long long rel = ANY ? __ballot(active) : __ballot(active && zc > kf);
+        if (ANY && rel == 0ull) break;
+        if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
+            if (level == 0) break;
+            --level;
+            const uint2 e = lds[level * 64 + lane];
+            key = e.x;
+            cref = e.y;
+            continue;
+        }
+        // Shrink the beam to the lanes that still matter once half of them have dropped out: the
+        // children tested from here on are culled against the thinner beam.
+        // (Shadow mode only: an occluded lane is finished for good. In nearest-hit mode a lane that
+        // is finished for this level can still be needed by a nearer child pending further out.)
+        const int n_rel = __builtin_popcountll(rel);
+        if (ANY && 2 * n_rel <= n_beam) {
+            BeamLane tmp;
+            make_beam(sv, o, d, active, b, tmp, false);
+            n_beam = n_rel;
+        }
+        const uint32_t sel = kmin & 63u;
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)sel);
+        if (lane == sel) key = 0xFFFFFFFFu;
+        if (r & LEAF_BIT) {
+            const float before = closest;
+            packet_leaf<ANY, STATS>(sv, r, obj_index, active, o, d, closest, local_best, hit, active, occluded, st);
+            if (!ANY) {
+                if (__ballot(closest < before) != 0ull) {
+                    zc = far_rel(closest);
+                    wend_rel = wave_max_f32(active ? zc : -RT_INF);
+                }
+            }
+        } else {
+            lds[level * 64 + lane] = make_uint2(key, cref);
+            ++level;
+            beam_node<STATS>(sv, r, b, wend_rel, lane, key, cref, st);
+        }
+    }
+}
+
 // The wave-coherent forms of closest_all / any_all. Every lane of the wave must call them
 // together; `active` says whether the lane carries a ray.
 template <bool STATS>
-__device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, LaneStats& st) {
+__device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, uint2* beam_lds,
+                                                   LaneStats& st) {
     const rt_f3 inv = g_recip(d);
     HitD h;
     h.tri = RT_MISS;
@@ -408,12 +623,19 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
         const f32x16_t ob = sload16(op);
         const rt_f3 bbmin = f3(ob[0], ob[1], ob[2]), bbmax = f3(ob[3], ob[4], ob[5]);
         const uint32_t tri_base = __float_as_uint(ob[6]), n_tris = __float_as_uint(ob[7]);
-        const uint32_t root = __float_as_uint(ob[9]);
+        const uint32_t wide_root = __float_as_uint(ob[8]), root = __float_as_uint(ob[9]);
         const uint32_t rest_base = __float_as_uint(ob[10]), n_rest = __float_as_uint(ob[11]);
         if (STATS && active) st.box += 1;
         const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
         if (RT_BALLOT(in_obj) == 0ull) continue;
-        if (root != EMPTY) packet_search<false, STATS>(sv, root, oi, o, d, inv, in_obj, closest, h, unused, st);
+        if (root != EMPTY) {
+            Beam beam;
+            BeamLane bl;
+            if (make_beam(sv, o, d, in_obj, beam, bl, true))
+                beam_search<false, STATS>(sv, wide_root, oi, o, d, in_obj, beam, bl, closest, h, unused, beam_lds, st);
+            else
+                packet_search<false, STATS>(sv, root, oi, o, d, inv, in_obj, closest, h, unused, st);
+        }
         for (uint32_t r = 0; r < n_rest; ++r) {
             const char* pv = reinterpret_cast<const char*>(sv.rest_verts) + 36 * (size_t)(rest_base + r);
             const f32x8_t va = sload8(pv);
@@ -437,7 +659,8 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
 }
 
 template <bool STATS>
-__device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, LaneStats& st) {
+__device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, uint2* beam_lds,
+                                               LaneStats& st) {
     const rt_f3 inv = g_recip(d);
     if (STATS && active) st.rays += 1;
     bool occluded = false;
@@ -446,7 +669,7 @@ __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_
         const char* op = reinterpret_cast<const char*>(sv.objs) + 64 * (size_t)oi;
         const f32x16_t ob = sload16(op);
         const rt_f3 bbmin = f3(ob[0], ob[1], ob[2]), bbmax = f3(ob[3], ob[4], ob[5]);
-        const uint32_t root = __float_as_uint(ob[9]);
+        const uint32_t wide_root = __float_as_uint(ob[8]), root = __float_as_uint(ob[9]);
         const uint32_t rest_base = __float_as_uint(ob[10]), n_rest = __float_as_uint(ob[11]);
         if (STATS && active) st.box += 1;
         const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
@@ -455,7 +678,12 @@ __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_
             float closest = RT_INF;
             HitD dummy;
             bool occ = false;
-            packet_search<true, STATS>(sv, root, oi, o, d, inv, in_obj, closest, dummy, occ, st);
+            Beam beam;
+            BeamLane bl;
+            if (make_beam(sv, o, d, in_obj, beam, bl, true))
+                beam_search<true, STATS>(sv, wide_root, oi, o, d, in_obj, beam, bl, closest, dummy, occ, beam_lds, st);
+            else
+                packet_search<true, STATS>(sv, root, oi, o, d, inv, in_obj, closest, dummy, occ, st);
             if (occ) {
                 occluded = true;
                 active = false;
@@ -545,7 +773,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest_linear(SceneView sv,
     for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
         const DevObject& ob = sv.objs[oi];
         if (!box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) continue;
-        const uint32_t n_leaves = ob.n_packed / 8;
+        const uint32_t n_leaves = ob.n_tris / 8;
         const uint32_t n_packets = n_leaves / 8;
         auto scan_leaf = [&](uint32_t leaf) {
             // PackedTriangles::intersect with ray_length = closest at entry, then the j loop.
@@ -781,15 +1009,21 @@ __device__ __forceinline__ void sample_offset(uint32_t grid, uint32_t s, float* 
 // diffuse bounces, which scatter, are traced per lane.
 // MODE 0: camera + shadow rays only (no reflective object or reflect_depth <= 1, diffuse_depth <= 1)
 // MODE 1: + mirror chains     MODE 2: + diffuse scattering at depth 1
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_render(SceneView sv, DevRenderParams p,
-                                                     const uint32_t* __restrict__ tile_list,
-                                                     uint8_t* __restrict__ rgba8, uint32_t* __restrict__ hit_ids,
-                                                     DevStats* __restrict__ stats) {
-    __shared__ uint2 s_stack[MODE > 0 ? RT_STACK_LDS * RT_BLOCK : 1];
-    __shared__ float s_col[3 * RT_BLOCK];
+template <int MODE, bool STATS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams p,
+                                                  const uint32_t* __restrict__ tile_list,
+                                                  uint8_t* __restrict__ rgba8, uint32_t* __restrict__ hit_ids,
+                                                  DevStats* __restrict__ stats) {
+    static_assert(MODE == 0 || BLOCK == RT_BLOCK, "per-lane stacks are laid out for RT_BLOCK threads");
+    // LDS: [per-lane stacks (MODE > 0)] [sample colours] [beam levels: one slab per wave]
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    constexpr int OFF_COL = MODE > 0 ? RT_STACK_LDS * RT_BLOCK * 8 : 0;
+    constexpr int OFF_BEAM = OFF_COL + 3 * BLOCK * 4;
+    uint2* s_stack = reinterpret_cast<uint2*>(s_dyn);
+    float* s_col = reinterpret_cast<float*>(s_dyn + OFF_COL);
+    uint2* s_beam = reinterpret_cast<uint2*>(s_dyn + OFF_BEAM) + (threadIdx.x >> 6) * p.beam_levels * 64;
     const uint32_t spp = p.spp;
-    const uint32_t ppb = RT_BLOCK / spp;                         // pixels per workgroup
+    const uint32_t ppb = BLOCK / spp;                            // pixels per workgroup
     const uint32_t blocks_per_tile = (RT_TILE * RT_TILE) / ppb;
     const uint32_t local_tile = blockIdx.x / blocks_per_tile;
     const uint32_t block_in_tile = blockIdx.x % blocks_per_tile;
@@ -821,14 +1055,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(SceneView sv, DevRenderPara
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
 
     // depth 1: nearest hit and direct light, src/main.rs:93-241.
-    const HitD h = closest_all_packet<STATS>(sv, o, d, inside, st);
+    const HitD h = closest_all_packet<STATS>(sv, o, d, inside, s_beam, st);
     const bool hit_any = inside && h.tri != RT_MISS;
     HitD hs = h;
     if (!hit_any) hs.tri = 0, hs.obj = 0;  // keep the loads below in range for idle lanes
     const Surface sf = surface_of(sv, hs, o, d);
     const rt_f3 sun_dir = g_normalize(sun - sf.pos);
     const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
-    const bool occluded = any_all_packet<STATS>(sv, sf.pos, sun_dir, lit, st);
+    const bool occluded = any_all_packet<STATS>(sv, sf.pos, sun_dir, lit, s_beam, st);
     Col color{0.0f, 0.0f, 0.0f};
     if (lit && !occluded) color = cmul(sf.color, g_dot(sf.normal, sun_dir) * sf.albedo);
 
@@ -883,6 +1117,178 @@ __global__ __launch_bounds__(RT_BLOCK) void k_render(SceneView sv, DevRenderPara
         size_t off;
         if (p.compact) off = ((size_t)local_tile * RT_TILE * RT_TILE + (size_t)my * RT_TILE + mx) * 4;
         else off = ((size_t)y * p.width + x) * 4;
+        *reinterpret_cast<uint32_t*>(rgba8 + off) = px;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera + shadow frames as three kernels with a sort in between (used when no ray bounces):
+//   k_wf_primary  camera rays (beam walk); per sample: hit point, hit id, state; a light-space
+//                 sort key for every sample that needs a shadow ray
+//   (radix sort of (key, sample slot) pairs)
+//   k_wf_shadow   shadow rays in light-space order: the 64 rays of a wave run along (nearly) the
+//                 same line towards the sun, so the beam walk stays thin even though their
+//                 origins lie at very different depths
+//   k_wf_resolve  shading, gamma, sub-sample average, RGBA8
+// Shading repeats the megakernel's arithmetic exactly (same operations on the same stored values).
+// ---------------------------------------------------------------------------------------------
+#define RT_ST_HIT 1u
+#define RT_ST_LIT 2u
+#define RT_ST_OCC 4u
+
+template <int BLOCK>
+struct PixelMap {
+    uint32_t x, y, s, mx, my, local_tile;
+    bool inside;
+    __device__ __forceinline__ PixelMap(const DevRenderParams& p, const uint32_t* tile_list) {
+        const uint32_t spp = p.spp;
+        const uint32_t ppb = BLOCK / spp;
+        const uint32_t blocks_per_tile = (RT_TILE * RT_TILE) / ppb;
+        local_tile = blockIdx.x / blocks_per_tile;
+        const uint32_t block_in_tile = blockIdx.x % blocks_per_tile;
+        const uint32_t tile = tile_list ? tile_list[local_tile] : local_tile;
+        const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+        s = threadIdx.x % spp;
+        const uint32_t pix_in_tile = block_in_tile * ppb + threadIdx.x / spp;
+        mx = 0;
+        my = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            mx |= ((pix_in_tile >> (2 * b)) & 1u) << b;
+            my |= ((pix_in_tile >> (2 * b + 1)) & 1u) << b;
+        }
+        x = tx * RT_TILE + mx;
+        y = ty * RT_TILE + my;
+        inside = x < p.width && y < p.height;
+    }
+};
+
+__device__ __forceinline__ rt_f3 camera_dir(const DevRenderParams& p, uint32_t x, uint32_t y, uint32_t s) {
+    float ox, oy;
+    sample_offset(p.grid, s, &ox, &oy);
+    // src/main.rs:314,322-330. aspect_ratio is an integer division in the reference.
+    const float aspect = (float)(p.width / p.height);
+    const float xx = (2.0f * ((float)x + ox) / (float)p.width - 1.0f) * aspect * 1.0f;
+    const float yy = (1.0f - 2.0f * ((float)y + oy) / (float)p.height) * 1.0f;
+    return f3(xx, yy, 1.0f);
+}
+
+__device__ __forceinline__ uint32_t spread16(uint32_t v) {
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+template <bool STATS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_wf_primary(SceneView sv, DevRenderParams p, LightProj lp,
+                                                      const uint32_t* __restrict__ tile_list,
+                                                      float4* __restrict__ samp, uint32_t* __restrict__ state,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      DevStats* __restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
+    const PixelMap<BLOCK> pm(p, tile_list);
+    LaneStats st;
+    const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    const HitD h = closest_all_packet<STATS>(sv, o, d, pm.inside, s_beam, st);
+    const bool hit_any = pm.inside && h.tri != RT_MISS;
+    HitD hs = h;
+    if (!hit_any) hs.tri = 0, hs.obj = 0;
+    const Surface sf = surface_of(sv, hs, o, d);
+    const rt_f3 sun_dir = g_normalize(sun - sf.pos);
+    const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(h.tri));
+    state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
+    // Light-space key: the hit point projected from the sun onto the plane across the light's
+    // dominant axis; points on one line to the sun get (nearly) one key.
+    uint32_t key = 0xFFFFFFFFu;
+    if (lit) {
+        const float pw = pick3(sf.pos, lp.w) - lp.sun_w;
+        const float rw = 1.0f / pw;
+        const float u = (pick3(sf.pos, lp.a1) - lp.sun_a1) * rw;
+        const float v = (pick3(sf.pos, lp.a2) - lp.sun_a2) * rw;
+        const float qu = fminf(fmaxf((u - lp.u0) * lp.uscale, 0.0f), 65535.0f);
+        const float qv = fminf(fmaxf((v - lp.v0) * lp.vscale, 0.0f), 65535.0f);
+        key = spread16((uint32_t)qu) | (spread16((uint32_t)qv) << 1);
+        if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
+    }
+    keys[slot] = key;
+    vals[slot] = slot;
+    if (STATS) flush_stats(st, stats);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
+                                                        const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals,
+                                                        const float4* __restrict__ samp, uint32_t* __restrict__ state,
+                                                        DevStats* __restrict__ stats) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool act = i < n && keys[i] != 0xFFFFFFFFu;
+    if (__ballot(act) == 0ull) return;  // keys are sorted: samples without a shadow ray come last
+    LaneStats st;
+    const uint32_t slot = act ? vals[i] : 0u;
+    const float4 a = samp[slot];
+    const rt_f3 pos = f3(a.x, a.y, a.z);
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    const rt_f3 sdir = g_normalize(sun - pos);
+    const bool occ = any_all_packet<STATS>(sv, pos, sdir, act, s_beam, st);
+    if (act && occ) state[slot] |= RT_ST_OCC;
+    if (STATS) flush_stats(st, stats);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_wf_resolve(SceneView sv, DevRenderParams p,
+                                                      const uint32_t* __restrict__ tile_list,
+                                                      const float4* __restrict__ samp,
+                                                      const uint32_t* __restrict__ state, uint8_t* __restrict__ rgba8,
+                                                      uint32_t* __restrict__ hit_ids) {
+    __shared__ float s_col[3 * BLOCK];
+    const PixelMap<BLOCK> pm(p, tile_list);
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const float4 a = samp[slot];
+    const uint32_t stt = state[slot];
+    const uint32_t tri = __float_as_uint(a.w);
+    const bool hit_any = (stt & RT_ST_HIT) != 0u;
+    Col color{0.0f, 0.0f, 0.0f};
+    if (hit_any) {
+        // src/main.rs:176-241 on the stored hit point: the same operations as in k_render.
+        const float* td = sv.tri_data + 6 * (size_t)tri;
+        const rt_f3 normal = ld3(td);
+        const Col tcol = Col{td[3], td[4], td[5]};
+        const rt_f3 pos = f3(a.x, a.y, a.z);
+        const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+        const rt_f3 sun_dir = g_normalize(sun - pos);
+        if ((stt & RT_ST_LIT) && !(stt & RT_ST_OCC))
+            color = cmul(tcol, g_dot(normal, sun_dir) * sv.objs[stt >> 8].albedo);
+        color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+    } else {
+        color = pm.inside ? sky() : Col{0.0f, 0.0f, 0.0f};
+    }
+    const uint32_t spp = p.spp;
+    if (hit_ids && pm.inside) hit_ids[((uint64_t)pm.y * p.width + pm.x) * spp + pm.s] = tri;
+    s_col[3 * threadIdx.x + 0] = color.r;
+    s_col[3 * threadIdx.x + 1] = color.g;
+    s_col[3 * threadIdx.x + 2] = color.b;
+    __syncthreads();
+    if (pm.s == 0 && pm.inside) {
+        Col acc = color;
+        for (uint32_t k = 1; k < spp; ++k) {
+            const float* c = &s_col[3 * (threadIdx.x + k)];
+            acc = cadd(acc, Col{c[0], c[1], c[2]});
+        }
+        acc = cdiv(acc, (float)spp);
+        const uint32_t px = to_u8(acc.r) | (to_u8(acc.g) << 8) | (to_u8(acc.b) << 16) | 0xff000000u;
+        size_t off;
+        if (p.compact) off = ((size_t)pm.local_tile * RT_TILE * RT_TILE + (size_t)pm.my * RT_TILE + pm.mx) * 4;
+        else off = ((size_t)pm.y * p.width + pm.x) * 4;
         *reinterpret_cast<uint32_t*>(rgba8 + off) = px;
     }
 }
@@ -958,22 +1364,62 @@ hipError_t gather_records(const float* d_tri9, const uint32_t* d_order, uint32_t
 
 hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, int mode,
                   uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats, hipStream_t s) {
-    const uint32_t ppb = RT_BLOCK / p.spp;
+    const uint32_t block = mode == 0 ? RT_BLOCK0 : RT_BLOCK;
+    const uint32_t ppb = block / p.spp;
     const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / ppb);
     if (blocks == 0) return hipSuccess;
-#define RT_LAUNCH(M, S)                                                                                          \
-    hipLaunchKernelGGL((k_render<M, S>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_rgba8, d_hit_ids, \
+    const size_t lds = (mode > 0 ? RT_STACK_LDS * RT_BLOCK * 8 : 0) + (size_t)block * 12 +
+                       (size_t)(block / 64) * p.beam_levels * 64 * 8;
+#define RT_LAUNCH(M, S, B)                                                                                        \
+    hipLaunchKernelGGL((k_render<M, S, B>), dim3(blocks), dim3(B), lds, s, sv, p, d_tile_list, d_rgba8, d_hit_ids, \
                        d_stats)
     if (d_stats) {
-        if (mode == 0) RT_LAUNCH(0, true);
-        else if (mode == 1) RT_LAUNCH(1, true);
-        else RT_LAUNCH(2, true);
+        if (mode == 0) RT_LAUNCH(0, true, RT_BLOCK0);
+        else if (mode == 1) RT_LAUNCH(1, true, RT_BLOCK);
+        else RT_LAUNCH(2, true, RT_BLOCK);
     } else {
-        if (mode == 0) RT_LAUNCH(0, false);
-        else if (mode == 1) RT_LAUNCH(1, false);
-        else RT_LAUNCH(2, false);
+        if (mode == 0) RT_LAUNCH(0, false, RT_BLOCK0);
+        else if (mode == 1) RT_LAUNCH(1, false, RT_BLOCK);
+        else RT_LAUNCH(2, false, RT_BLOCK);
     }
 #undef RT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
+                      float4* d_samp, uint32_t* d_state, uint32_t* d_keys, uint32_t* d_vals, DevStats* d_stats,
+                      hipStream_t s) {
+    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
+    if (blocks == 0) return hipSuccess;
+    const size_t lds = (size_t)(RT_BLOCK / 64) * p.beam_levels * 64 * 8;
+    if (d_stats)
+        hipLaunchKernelGGL((k_wf_primary<true, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), lds, s, sv, p, lp, d_tile_list,
+                           d_samp, d_state, d_keys, d_vals, d_stats);
+    else
+        hipLaunchKernelGGL((k_wf_primary<false, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), lds, s, sv, p, lp, d_tile_list,
+                           d_samp, d_state, d_keys, d_vals, d_stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, const uint32_t* d_keys,
+                     const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state, DevStats* d_stats, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t lds = (size_t)(RT_BLOCK / 64) * p.beam_levels * 64 * 8;
+    if (d_stats)
+        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, d_keys,
+                           d_vals, d_samp, d_state, d_stats);
+    else
+        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, d_keys,
+                           d_vals, d_samp, d_state, d_stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
+                      const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s) {
+    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_wf_resolve<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_samp, d_state,
+                       d_rgba8, d_hit_ids);
     return hipGetLastError();
 }
 
