@@ -198,6 +198,16 @@ def main():
         alg_bytes = 28 * n_samples_rank + BYTES_BOX * my_box + BYTES_TRI * my_tri
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
+        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (collected with
+        # rocprofv3, not live): only quoted for the workload it was measured on.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if world == 1 and (args.tris, args.seed, W, H) == (1_000_000, 0x5EED0001, 3840, 2160):
+                traffic = pm["bytes_per_launch"]
+        except OSError:
+            pass
         out = {
             "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays)",
             "value": value,
@@ -229,7 +239,7 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel_ms": kernel_ms,
                 "alg_bytes_per_launch": alg_bytes,
                 "valu_tflops": alg_flops / (kernel_ms * 1e-3) / 1e12,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir-name> <counters...>   (run on the GPU box from the repo root)
+# usage: tools/pmc.sh <outdir-name> <counters...>   (run on the GPU box from the repo root)
 set -e
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp
