@@ -500,7 +500,7 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
     HIP_TRY(pool.alloc((void**)&d_leaf_bounds, leaf_first.size() * 24));
     HIP_TRY(pool.alloc((void**)&d_data, data_all.size() * 4));
     HIP_TRY(pool.alloc((void**)&d_rest, rest_verts.size() * 4));
-    HIP_TRY(pool.alloc((void**)&d_recs, order_all.size() * 48));
+    HIP_TRY(pool.alloc((void**)&d_recs, order_all.size() * 48 + 192));  // padded: a leaf is read as 192 B
     HIP_TRY(pool.alloc((void**)&d_nodes, nodes_all.size() * sizeof(rtbvh::Node4)));
     HIP_TRY(pool.alloc((void**)&d_wide, wide_all.size() * sizeof(rtbvh::Child)));
     HIP_TRY(pool.alloc((void**)&d_objs, s->objects.size() * sizeof(DevObject)));

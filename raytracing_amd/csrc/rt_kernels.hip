@@ -402,26 +402,31 @@ __device__ __forceinline__ void packet_search(const SceneView& sv, uint32_t root
 // (key, reference) per lane; the nearest pending child is found with a DPP wave-minimum, and a
 // child is dropped without a visit once its entry distance lies beyond every ray's nearest hit.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+// Wave reductions with DPP-fused VALU ops: row_shr:1,2,4,8 leave each row's result in its last
+// lane, row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3) carry it to lane 63. A lane whose DPP
+// source is out of range is skipped by the hardware and keeps its value. The s_nop 1 between the
+// steps are the two wait states a DPP read needs after a VALU write of the same register.
+#define RT_DPP_REDUCE(OP)                                                       \
+    "s_nop 1\n\t"                                                               \
+    OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+    OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+    OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+    OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+    OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"     \
+    OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    asm volatile(RT_DPP_REDUCE("v_min_u32_dpp") : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-// row_shr:1,2,4,8 then row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3): lane 63 ends up with the
-// reduction over the wave.
-#define RT_WAVE_REDUCE(T, OP, FROM_I, TO_I)                       \
-    v = OP(v, FROM_I(dpp_i<0x111, 0xF>(TO_I(v))));                \
-    v = OP(v, FROM_I(dpp_i<0x112, 0xF>(TO_I(v))));                \
-    v = OP(v, FROM_I(dpp_i<0x114, 0xF>(TO_I(v))));                \
-    v = OP(v, FROM_I(dpp_i<0x118, 0xF>(TO_I(v))));                \
-    v = OP(v, FROM_I(dpp_i<0x142, 0xA>(TO_I(v))));                \
-    v = OP(v, FROM_I(dpp_i<0x143, 0xC>(TO_I(v))));                \
-    return FROM_I(__builtin_amdgcn_readlane(TO_I(v), 63));
-__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ int id_i(int x) { return x; }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { RT_WAVE_REDUCE(uint32_t, umin_, (uint32_t), (int)) }
-__device__ __forceinline__ float wave_min_f32(float v) { RT_WAVE_REDUCE(float, fminf, __int_as_float, __float_as_int) }
-__device__ __forceinline__ float wave_max_f32(float v) { RT_WAVE_REDUCE(float, fmaxf, __int_as_float, __float_as_int) }
-#undef RT_WAVE_REDUCE
+__device__ __forceinline__ float wave_min_f32(float v) {
+    asm volatile(RT_DPP_REDUCE("v_min_f32_dpp") : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    asm volatile(RT_DPP_REDUCE("v_max_f32_dpp") : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef RT_DPP_REDUCE
 
 // The beam of a wave, wave-uniform. Rays are written along their dominant axis w (the axis with
 // the largest direction component, mirrored so that every ray travels towards +w): on each of
@@ -431,11 +436,8 @@ __device__ __forceinline__ float wave_max_f32(float v) { RT_WAVE_REDUCE(float, f
 // parallel rays starting anywhere along a line (sun shadow rays: B is one value and A barely
 // moves, however far apart the origins are in depth).
 struct Beam {
-    int m;            // dominant axis 0..2
-    float sgn;        // +1 or -1: w = sgn * coord_m
-    int ax[2];        // the two lateral axes
-    float a0[2], a1[2], b0[2], b1[2];
-    float amax[2], bmax[2];  // largest magnitudes, for the rounding margin
+    float sgn;        // +1 or -1: w = sgn * coord_M (M = dominant axis, a template parameter)
+    float a0[2], a1[2], b0[2], b1[2];  // over the lateral axes (M+1)%3... see lat_axis
     float wbase;      // w of the first origin when the walk started: keys are w - wbase
     float wstart;     // smallest origin w among the lanes the beam covers
 };
@@ -443,52 +445,64 @@ struct Beam {
 #define RT_MARGIN 9.5367431640625e-7f  // 2^-20
 #define RT_MAX_SLOPE 8.0f
 
+template <int K>
+__device__ __forceinline__ float comp(const rt_f3& v) { return K == 0 ? v.x : (K == 1 ? v.y : v.z); }
 __device__ __forceinline__ float pick3(const rt_f3& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+// Lateral axes of dominant axis M: (1,2), (0,2), (0,1).
+template <int M, int K>
+struct lat_axis {
+    static constexpr int value = K == 0 ? (M == 0 ? 1 : 0) : (M == 2 ? 1 : 2);
+};
 
 // Per-lane line coefficients of the beam form.
 struct BeamLane {
     float ow, dw;  // origin and direction along w (dw > 0)
 };
 
-// Builds the beam of the active lanes. Returns false (wave-uniform) when the rays do not all
-// travel the same way along one common dominant axis, a lateral slope exceeds RT_MAX_SLOPE, or a
-// value is not finite; the caller then uses packet_search. `first` keeps the axis choice and
-// wbase of an earlier build (a refit over fewer lanes).
+// Dominant axis of the first active lane's direction (wave-uniform), and its sign.
+__device__ __forceinline__ int beam_axis(rt_f3 d, unsigned long long act, float* sgn) {
+    const int l0 = __builtin_ctzll(act);
+    const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.x), l0));
+    const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.y), l0));
+    const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.z), l0));
+    const float ax = __builtin_fabsf(dx), ay = __builtin_fabsf(dy), az = __builtin_fabsf(dz);
+    const int m = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    *sgn = (m == 0 ? dx : (m == 1 ? dy : dz)) < 0.0f ? -1.0f : 1.0f;
+    return m;
+}
+
+// Builds the beam of the active lanes along dominant axis M (b.sgn set by the caller). Returns
+// false (wave-uniform) when some ray does not travel towards +w, a lateral slope exceeds
+// RT_MAX_SLOPE, a value is not finite, or the beam is too wide to be worth a beam walk; the caller
+// then uses packet_search. `first` = false keeps wbase of an earlier build (a refit over fewer lanes).
+template <int M>
 __device__ __forceinline__ bool make_beam(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, Beam& b, BeamLane& bl,
                                           bool first) {
-    const unsigned long long act = __ballot(active);
-    if (act == 0ull) return false;
-    if (first) {
-        const int l0 = __builtin_ctzll(act);
-        const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.x), l0));
-        const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.y), l0));
-        const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.z), l0));
-        const float ax = __builtin_fabsf(dx), ay = __builtin_fabsf(dy), az = __builtin_fabsf(dz);
-        b.m = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-        b.sgn = (b.m == 0 ? dx : (b.m == 1 ? dy : dz)) < 0.0f ? -1.0f : 1.0f;
-        b.ax[0] = b.m == 0 ? 1 : 0;
-        b.ax[1] = b.m == 2 ? 1 : 2;
-    }
-    bl.ow = b.sgn * pick3(o, b.m);
-    bl.dw = b.sgn * pick3(d, b.m);
-    bool lane_ok = bl.dw > 0.0f && bl.dw < RT_INF && __builtin_fabsf(bl.ow) < RT_INF;
+    bl.ow = b.sgn * comp<M>(o);
+    bl.dw = b.sgn * comp<M>(d);
+    bool lane_ok = (bl.dw > 0.0f) & (bl.dw < RT_INF) & (__builtin_fabsf(bl.ow) < RT_INF);
     const float rdw = 1.0f / bl.dw;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float oa = pick3(o, b.ax[k]), da = pick3(d, b.ax[k]);
-        const float B = da * rdw;
-        const float A = oa - B * bl.ow;
-        lane_ok = lane_ok && __builtin_fabsf(B) <= RT_MAX_SLOPE && __builtin_fabsf(A) < RT_INF;
-        // rounding of B and of A = oa - B * ow, plus a relative cushion
-        const float eB = __builtin_fabsf(B) * (4.0f * RT_MARGIN);
-        const float eA = (__builtin_fabsf(oa) + __builtin_fabsf(B * bl.ow)) * (4.0f * RT_MARGIN) + 1e-30f;
-        const bool use = active && lane_ok;
-        b.a0[k] = wave_min_f32(use ? A - eA : RT_INF);
-        b.a1[k] = wave_max_f32(use ? A + eA : -RT_INF);
-        b.b0[k] = wave_min_f32(use ? B - eB : RT_INF);
-        b.b1[k] = wave_max_f32(use ? B + eB : -RT_INF);
-        b.amax[k] = fmaxf(__builtin_fabsf(b.a0[k]), __builtin_fabsf(b.a1[k]));
-        b.bmax[k] = fmaxf(__builtin_fabsf(b.b0[k]), __builtin_fabsf(b.b1[k]));
+    {
+        const float oa = comp<lat_axis<M, 0>::value>(o), da = comp<lat_axis<M, 0>::value>(d);
+        const float ob = comp<lat_axis<M, 1>::value>(o), db = comp<lat_axis<M, 1>::value>(d);
+        const float B0 = da * rdw, B1 = db * rdw;
+        const float A0 = oa - B0 * bl.ow, A1 = ob - B1 * bl.ow;
+        lane_ok = lane_ok & (__builtin_fabsf(B0) <= RT_MAX_SLOPE) & (__builtin_fabsf(A0) < RT_INF) &
+                  (__builtin_fabsf(B1) <= RT_MAX_SLOPE) & (__builtin_fabsf(A1) < RT_INF);
+        // rounding of B and of A = oa - B * ow, plus a relative cushion that also covers the
+        // roundings of the node test (products and sums, 2^-24 relative each)
+        const float eB0 = __builtin_fabsf(B0) * (4.0f * RT_MARGIN), eB1 = __builtin_fabsf(B1) * (4.0f * RT_MARGIN);
+        const float eA0 = (__builtin_fabsf(oa) + __builtin_fabsf(B0 * bl.ow)) * (4.0f * RT_MARGIN) + 1e-30f;
+        const float eA1 = (__builtin_fabsf(ob) + __builtin_fabsf(B1 * bl.ow)) * (4.0f * RT_MARGIN) + 1e-30f;
+        const bool use = active & lane_ok;
+        b.a0[0] = wave_min_f32(use ? A0 - eA0 : RT_INF);
+        b.a1[0] = wave_max_f32(use ? A0 + eA0 : -RT_INF);
+        b.b0[0] = wave_min_f32(use ? B0 - eB0 : RT_INF);
+        b.b1[0] = wave_max_f32(use ? B0 + eB0 : -RT_INF);
+        b.a0[1] = wave_min_f32(use ? A1 - eA1 : RT_INF);
+        b.a1[1] = wave_max_f32(use ? A1 + eA1 : -RT_INF);
+        b.b0[1] = wave_min_f32(use ? B1 - eB1 : RT_INF);
+        b.b1[1] = wave_max_f32(use ? B1 + eB1 : -RT_INF);
     }
     const float ws = wave_min_f32(active ? bl.ow : RT_INF);
     b.wstart = ws - __builtin_fabsf(ws) * RT_MARGIN;
@@ -508,7 +522,7 @@ __device__ __forceinline__ bool make_beam(const SceneView& sv, rt_f3 o, rt_f3 d,
 // and wend_rel (the farthest w, relative to wbase, at which any ray can still gain a hit).
 // key = entry w relative to wbase with the lane number in its low six bits (0xFFFFFFFF: no
 // visit), cref = the child's reference.
-template <bool STATS>
+template <int M, bool STATS>
 __device__ __forceinline__ void beam_node(const SceneView& sv, uint32_t ref, const Beam& b, float wend_rel,
                                           uint32_t lane, uint32_t& key, uint32_t& cref, LaneStats& st) {
     const uint32_t first = ref >> 6, count = (ref & 63u) + 1u;
@@ -522,30 +536,37 @@ __device__ __forceinline__ void beam_node(const SceneView& sv, uint32_t ref, con
         const float4* cp = reinterpret_cast<const float4*>(sv.wide + first + lane);
         const float4 A = cp[0], B = cp[1];  // (lo.x lo.y lo.z hi.x) (hi.y hi.z ref pad)
         const rt_f3 lo = f3(A.x, A.y, A.z), hi = f3(A.w, B.x, B.y);
-        const float lm = pick3(lo, b.m), hm = pick3(hi, b.m);
+        const float lm = comp<M>(lo), hm = comp<M>(hi);
         const float z0 = fmaxf(b.sgn > 0.0f ? lm : -hm, b.wstart);
         const float z1 = fminf(b.sgn > 0.0f ? hm : -lm, b.wbase + wend_rel);
         bool hit = z0 <= z1;
-        const float zabs = fmaxf(__builtin_fabsf(z0), __builtin_fabsf(z1));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float p00 = b.b0[k] * z0, p01 = b.b0[k] * z1, p10 = b.b1[k] * z0, p11 = b.b1[k] * z1;
-            const float e = __builtin_fmaf(b.bmax[k], zabs, b.amax[k]) * (4.0f * RT_MARGIN);
-            const float blo = b.a0[k] + fminf(fminf(p00, p01), fminf(p10, p11)) - e;
-            const float bhi = b.a1[k] + fmaxf(fmaxf(p00, p01), fmaxf(p10, p11)) + e;
-            hit = hit && blo <= pick3(hi, b.ax[k]) && bhi >= pick3(lo, b.ax[k]);
+        {
+            const float p00 = b.b0[0] * z0, p01 = b.b0[0] * z1, p10 = b.b1[0] * z0, p11 = b.b1[0] * z1;
+            const float blo = b.a0[0] + fminf(fminf(p00, p01), fminf(p10, p11));
+            const float bhi = b.a1[0] + fmaxf(fmaxf(p00, p01), fmaxf(p10, p11));
+            hit = hit & (blo <= comp<lat_axis<M, 0>::value>(hi)) & (bhi >= comp<lat_axis<M, 0>::value>(lo));
         }
-        if (hit) {
-            key = (__float_as_uint(fmaxf(z0 - b.wbase, 0.0f)) & ~63u) | lane;
-            cref = __float_as_uint(B.z);
+        {
+            const float p00 = b.b0[1] * z0, p01 = b.b0[1] * z1, p10 = b.b1[1] * z0, p11 = b.b1[1] * z1;
+            const float blo = b.a0[1] + fminf(fminf(p00, p01), fminf(p10, p11));
+            const float bhi = b.a1[1] + fmaxf(fmaxf(p00, p01), fmaxf(p10, p11));
+            hit = hit & (blo <= comp<lat_axis<M, 1>::value>(hi)) & (bhi >= comp<lat_axis<M, 1>::value>(lo));
         }
+        key = hit ? ((__float_as_uint(fmaxf(z0 - b.wbase, 0.0f)) & ~63u) | lane) : 0xFFFFFFFFu;
+        cref = __float_as_uint(B.z);
     }
 }
 
-template <bool ANY, bool STATS>
-__device__ __forceinline__ void beam_search(const SceneView& sv, uint32_t root_ref, uint32_t obj_index, rt_f3 o, rt_f3 d,
-                                            bool active, Beam& b, BeamLane bl, float& closest, HitD& hit,
-                                            bool& occluded, uint2* lds, LaneStats& st) {
+// Beam walk of one object's wide tree along dominant axis M. Returns false without doing
+// anything when the wave's rays do not form a usable beam.
+template <bool ANY, bool STATS, int M>
+__device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_ref, uint32_t obj_index, rt_f3 o, rt_f3 d,
+                                            bool active, float sgn, float& closest, HitD& hit, bool& occluded,
+                                            uint2* lds, LaneStats& st) {
+    Beam b;
+    BeamLane bl;
+    b.sgn = sgn;
+    if (!make_beam<M>(sv, o, d, active, b, bl, true)) return false;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t local_best = 0;
     // Farthest useful w per lane, relative to wbase: where the ray's current nearest hit lies.
@@ -558,13 +579,13 @@ __device__ __forceinline__ void beam_search(const SceneView& sv, uint32_t root_r
     int n_beam = __builtin_popcountll(__ballot(active));  // lanes the current beam was built from
     int level = 0;
     uint32_t key, cref;
-    beam_node<STATS>(sv, root_ref, b, wend_rel, lane, key, cref, st);
+    beam_node<M, STATS>(sv, root_ref, b, wend_rel, lane, key, cref, st);
     for (;;) {
         const uint32_t kmin = wave_min_u32(key);
         const float kf = __uint_as_float(kmin & ~63u);
         // Lanes that can still gain from pending children: all unoccluded lanes in shadow mode;
         // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
-        // walk is front to back along w, so the others are finished).
+        // walk is front to back along w, so the others are finished for this level).
         const unsigned long long rel = ANY ? __ballot(active) : __ballot(active && zc > kf);
         if (ANY && rel == 0ull) break;
         if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
@@ -575,14 +596,14 @@ __device__ __forceinline__ void beam_search(const SceneView& sv, uint32_t root_r
             cref = e.y;
             continue;
         }
-        // Shrink the beam to the lanes that still matter once half of them have dropped out: the
-        // children tested from here on are culled against the thinner beam.
-        // (Shadow mode only: an occluded lane is finished for good. In nearest-hit mode a lane that
-        // is finished for this level can still be needed by a nearer child pending further out.)
+        // Shadow mode: shrink the beam to the unoccluded lanes once half of them have dropped out;
+        // the children tested from here on are culled against the thinner beam. (An occluded lane
+        // is finished for good. In nearest-hit mode a lane that is finished for this level can
+        // still be needed by a nearer child pending further out, so the beam is kept.)
         const int n_rel = __builtin_popcountll(rel);
         if (ANY && 2 * n_rel <= n_beam) {
             BeamLane tmp;
-            make_beam(sv, o, d, active, b, tmp, false);
+            make_beam<M>(sv, o, d, active, b, tmp, false);
             n_beam = n_rel;
         }
         const uint32_t sel = kmin & 63u;
@@ -600,9 +621,24 @@ __device__ __forceinline__ void beam_search(const SceneView& sv, uint32_t root_r
         } else {
             lds[level * 64 + lane] = make_uint2(key, cref);
             ++level;
-            beam_node<STATS>(sv, r, b, wend_rel, lane, key, cref, st);
+            beam_node<M, STATS>(sv, r, b, wend_rel, lane, key, cref, st);
         }
     }
+    return true;
+}
+
+// Picks the dominant axis and runs the beam walk; false when the wave needs the per-ray walk.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool beam_try(const SceneView& sv, uint32_t root_ref, uint32_t obj_index, rt_f3 o, rt_f3 d,
+                                         bool active, float& closest, HitD& hit, bool& occluded, uint2* lds,
+                                         LaneStats& st) {
+    const unsigned long long act = __ballot(active);
+    if (act == 0ull) return true;
+    float sgn;
+    const int m = beam_axis(d, act, &sgn);
+    if (m == 0) return beam_search<ANY, STATS, 0>(sv, root_ref, obj_index, o, d, active, sgn, closest, hit, occluded, lds, st);
+    if (m == 1) return beam_search<ANY, STATS, 1>(sv, root_ref, obj_index, o, d, active, sgn, closest, hit, occluded, lds, st);
+    return beam_search<ANY, STATS, 2>(sv, root_ref, obj_index, o, d, active, sgn, closest, hit, occluded, lds, st);
 }
 
 // The wave-coherent forms of closest_all / any_all. Every lane of the wave must call them
@@ -629,11 +665,7 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
         const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
         if (RT_BALLOT(in_obj) == 0ull) continue;
         if (root != EMPTY) {
-            Beam beam;
-            BeamLane bl;
-            if (make_beam(sv, o, d, in_obj, beam, bl, true))
-                beam_search<false, STATS>(sv, wide_root, oi, o, d, in_obj, beam, bl, closest, h, unused, beam_lds, st);
-            else
+            if (!beam_try<false, STATS>(sv, wide_root, oi, o, d, in_obj, closest, h, unused, beam_lds, st))
                 packet_search<false, STATS>(sv, root, oi, o, d, inv, in_obj, closest, h, unused, st);
         }
         for (uint32_t r = 0; r < n_rest; ++r) {
@@ -678,11 +710,7 @@ __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_
             float closest = RT_INF;
             HitD dummy;
             bool occ = false;
-            Beam beam;
-            BeamLane bl;
-            if (make_beam(sv, o, d, in_obj, beam, bl, true))
-                beam_search<true, STATS>(sv, wide_root, oi, o, d, in_obj, beam, bl, closest, dummy, occ, beam_lds, st);
-            else
+            if (!beam_try<true, STATS>(sv, wide_root, oi, o, d, in_obj, closest, dummy, occ, beam_lds, st))
                 packet_search<true, STATS>(sv, root, oi, o, d, inv, in_obj, closest, dummy, occ, st);
             if (occ) {
                 occluded = true;
@@ -1182,8 +1210,13 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v) {
     return v;
 }
 
+// Minimum waves per SIMD the camera- and shadow-ray kernels are compiled for: 8 keeps them at
+// <= 64 VGPRs, which measured 10 % faster than the 81 VGPRs the compiler picks unconstrained.
+#ifndef RT_WF_WAVES
+#define RT_WF_WAVES 8
+#endif
 template <bool STATS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_wf_primary(SceneView sv, DevRenderParams p, LightProj lp,
+__global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv, DevRenderParams p, LightProj lp,
                                                       const uint32_t* __restrict__ tile_list,
                                                       float4* __restrict__ samp, uint32_t* __restrict__ state,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -1223,7 +1256,7 @@ __global__ __launch_bounds__(BLOCK) void k_wf_primary(SceneView sv, DevRenderPar
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
+__global__ __launch_bounds__(RT_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
                                                         const uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals,
                                                         const float4* __restrict__ samp, uint32_t* __restrict__ state,
