@@ -188,14 +188,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total * args.steps / elapsed / 1e6
-        # Roofline of the frame kernel on this rank (per launch): algorithmic bytes = frame bytes
-        # written + structure bytes of the slab and triangle tests the launch performs.
-        # Dominant kernel = the camera-ray kernel (k_wf_primary). Per launch it writes 28 B per sample
-        # (hit point + id 16 B, state 4 B, sort key 4 B, sort value 4 B); camera rays are generated on
-        # the device (0 B in); structure bytes follow its own slab / triangle test counters.
+        # Roofline of the dominant kernel, the camera-ray kernel (k_wf_primary), per launch.
+        # Algorithmic bytes = what the launch has to move: 28 B written per sample (hit point + id
+        # 16 B, state 4 B, sort key 4 B, sort value 4 B; camera rays are generated on the device,
+        # 0 B in) + the tree-node and triangle-record bytes its loads request (32 B per child box
+        # tested, 48 B per triangle record; a load that serves a whole wave counts once), from the
+        # kernel's own counters in the instrumented build. The tests-per-ray formula
+        # 32 B * box tests + 36 B * triangle tests is kept beside it as "per_ray_structure_bytes":
+        # it prices every ray's test as if the ray had fetched its operands itself.
         my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
         n_samples_rank = st["primary_rays"]
-        alg_bytes = 28 * n_samples_rank + BYTES_BOX * my_box + BYTES_TRI * my_tri
+        alg_bytes = 28 * n_samples_rank + st["primary_fetch_bytes"]
+        per_ray_structure_bytes = BYTES_BOX * my_box + BYTES_TRI * my_tri
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (collected with
@@ -242,6 +246,7 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": kernel_ms,
                 "alg_bytes_per_launch": alg_bytes,
+                "per_ray_structure_bytes": per_ray_structure_bytes,
                 "valu_tflops": alg_flops / (kernel_ms * 1e-3) / 1e12,
                 "valu_frac": alg_flops / (kernel_ms * 1e-3) / FP32_PEAK,
             },

@@ -88,6 +88,9 @@ typedef struct {
     uint64_t tri_tests;   /* ray / triangle tests                                            */
     uint64_t node_visits; /* inner-node fetches                                              */
     uint64_t primary_rays, primary_box_tests, primary_tri_tests, primary_node_visits;
+    uint64_t fetch_bytes; /* bytes of tree nodes and triangle records the loads request: a load
+                             shared by a wave counts once, a per-ray load once per ray        */
+    uint64_t primary_fetch_bytes;
 } rt_stats;
 
 /* Number of events rt_render_device_events records. */

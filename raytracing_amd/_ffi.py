@@ -62,6 +62,8 @@ class rt_stats(C.Structure):
         ("primary_box_tests", C.c_uint64),
         ("primary_tri_tests", C.c_uint64),
         ("primary_node_visits", C.c_uint64),
+        ("fetch_bytes", C.c_uint64),
+        ("primary_fetch_bytes", C.c_uint64),
     ]
 
 

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -15,6 +16,24 @@ namespace {
 
 constexpr int BINS = 16;
 constexpr float PAD_REL = 6e-6f;  // relative widening of every triangle box, per axis
+
+// Tuning knobs (environment, read once): largest leaf and the price of one traversal step in
+// triangle tests.
+uint32_t max_leaf() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("RAYS_HIP_MAX_LEAF");
+        const long x = e ? std::atol(e) : (long)MAX_LEAF;
+        return (uint32_t)std::min<long>(std::max<long>(x, 1), 8);
+    }();
+    return v;
+}
+float trav_cost() {
+    static const float v = [] {
+        const char* e = std::getenv("RAYS_HIP_TRAV_COST");
+        return e ? (float)std::atof(e) : 1.0f;
+    }();
+    return v;
+}
 
 struct Prim {
     float lo[3], hi[3], c[3];
@@ -88,7 +107,7 @@ class Builder {
         }
 
         if (balanced_) {
-            if (n <= MAX_LEAF) {
+            if (n <= max_leaf()) {
                 node.first = begin;
                 node.count = n;
                 return me;
@@ -164,10 +183,10 @@ class Builder {
         }
 
         const float area = bb.half_area();
-        if (n <= MAX_LEAF) {
+        if (n <= max_leaf()) {
             // Leaf unless the split is clearly cheaper (traversal step priced at one triangle test).
             const float leaf_cost = (float)n;
-            const float split_cost = (best_axis >= 0 && area > 0.0f) ? 1.0f + best_cost / area : FLT_MAX;
+            const float split_cost = (best_axis >= 0 && area > 0.0f) ? trav_cost() + best_cost / area : FLT_MAX;
             if (!(split_cost < leaf_cost)) {
                 node.first = begin;
                 node.count = n;

@@ -235,7 +235,8 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (w.capacity < n_slots) {
         w.release();
         size_t tb = 0;
-        HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n_slots, stream));
+        // The temporary size is asked for the widest key, so one workspace serves every frame size.
+        HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n_slots, 32, stream));
         HIP_TRY(hipMalloc((void**)&w.samp, n_slots * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&w.state, n_slots * 4));
         for (int k = 0; k < 2; ++k) {
@@ -248,6 +249,20 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     }
     // Projection from the sun across its dominant axis, scaled to the scene's bounds.
     LightProj lp{};
+    // Only the leading bits of the interleaved key are kept and sorted: the sort is stable, so the
+    // rays of one cell keep their screen order, which is coherent enough within a cell of a few
+    // hundred rays, and each 8 bits less saves one pass over the pairs. Key bits = log2(n / 512)
+    // rounded up to an even number, at least 8.
+    {
+        static const long env_bits = [] {
+            const char* e = std::getenv("RAYS_HIP_SORT_BITS");
+            return e ? std::atol(e) : 0L;
+        }();
+        uint32_t kb = 8;
+        while (kb < 32 && ((size_t)512 << kb) < n_slots) kb += 2;
+        if (env_bits >= 2 && env_bits <= 32) kb = (uint32_t)env_bits & ~1u;
+        lp.key_bits = kb;
+    }
     {
         float c[3], dsun[3];
         for (int k = 0; k < 3; ++k) {
@@ -287,9 +302,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
     }
     size_t tb = w.temp_bytes;
-    HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], w.vals[0], w.vals[1], n_slots, stream));
+    HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], w.vals[0], w.vals[1], n_slots, lp.key_bits, stream));
     HIP_TRY(mark(2));
-    HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, w.keys[1], w.vals[1], w.samp, w.state, d_stats, stream));
+    HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1], w.vals[1], w.samp, w.state, d_stats, stream));
     HIP_TRY(mark(3));
     HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
     HIP_TRY(mark(4));
@@ -682,10 +697,17 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     stats->box_tests = h.box_tests;
     stats->tri_tests = h.tri_tests;
     stats->node_visits = h.node_visits;
+    stats->fetch_bytes = h.fetch_bytes;
     stats->primary_rays = hp.rays;
     stats->primary_box_tests = hp.box_tests;
     stats->primary_tri_tests = hp.tri_tests;
     stats->primary_node_visits = hp.node_visits;
+    stats->primary_fetch_bytes = hp.fetch_bytes;
+    if (std::getenv("RAYS_HIP_VERBOSE"))
+        std::fprintf(stderr,
+                     "rays_hip: camera kernel: %llu beam walks, %llu mask walks, %llu refits, %llu mask-walk nodes; "
+                     "frame: %llu / %llu / %llu / %llu\n",
+                     hp.walks[0], hp.walks[1], hp.walks[2], hp.walks[3], h.walks[0], h.walks[1], h.walks[2], h.walks[3]);
     return RT_OK;
 }
 

@@ -64,10 +64,12 @@ struct LightProj {
     int w, a1, a2;                 // dominant axis of (scene centre - sun) and the two others
     float sun_w, sun_a1, sun_a2;   // sun position on those axes
     float u0, uscale, v0, vscale;  // quantisation of the projected coordinates to 16 bits each
+    uint32_t key_bits;             // leading bits of the 32-bit interleaved key that are kept (even, 8..32)
 };
 
 struct DevStats {
-    unsigned long long rays, box_tests, tri_tests, node_visits;
+    unsigned long long rays, box_tests, tri_tests, node_visits, fetch_bytes;
+    unsigned long long walks[4];  // beam walks, mask walks, beam refits, mask-walk node fetches (per wave)
 };
 
 #endif

@@ -25,13 +25,15 @@ hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t*
 hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
                       float4* d_samp, uint32_t* d_state, uint32_t* d_keys, uint32_t* d_vals, DevStats* d_stats,
                       hipStream_t s);
-hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, const uint32_t* d_keys,
-                     const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state, DevStats* d_stats, hipStream_t s);
+hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
+                     const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
+                     DevStats* d_stats, hipStream_t s);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
-// Radix sort of (u32 key, u32 value) pairs. With temp == nullptr only *temp_bytes is set.
+// Stable radix sort of (u32 key, u32 value) pairs on the low key_bits bits of the key. With
+// temp == nullptr only *temp_bytes is set.
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                          const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s);
+                          const uint32_t* vals_in, uint32_t* vals_out, size_t n, unsigned key_bits, hipStream_t s);
 hipError_t deinterleave(const uint8_t* d_gathered, const uint32_t* d_tile_slot, uint32_t slab_tiles, uint32_t width,
                         uint32_t height, uint32_t tiles_x, uint32_t n_tiles_total, uint32_t shard_count,
                         uint8_t* d_rgba8, hipStream_t s);

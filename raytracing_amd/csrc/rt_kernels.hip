@@ -18,6 +18,8 @@ namespace {
 
 struct LaneStats {
     uint32_t box = 0, tri = 0, node = 0, rays = 0;
+    uint32_t walks[4] = {0, 0, 0, 0};  // lane 0 only: beam walks, mask walks, beam refits, mask-walk node fetches
+    uint32_t bytes = 0;  // structure bytes requested: a scalar load counts once per wave, a vector load per lane
 };
 
 struct HitD {
@@ -86,6 +88,7 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
             if (STATS) {
                 st.node += 1;
                 st.box += 4;
+                st.bytes += 128;
             }
             float k0, k1, k2, k3;
             uint32_t c0 = __float_as_uint(b0.z), c1 = __float_as_uint(b1.z);
@@ -126,7 +129,10 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
                 const rt_f3 e1 = f3(ra.w, rb.x, rb.y);
                 const rt_f3 e2 = f3(rb.z, rb.w, rc.x);
                 const uint32_t id = __float_as_uint(rc.y);
-                if (STATS) st.tri += 1;
+                if (STATS) {
+                    st.tri += 1;
+                    st.bytes += 48;
+                }
                 const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
                 if (ANY) {
                     if (!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) return true;
@@ -289,6 +295,7 @@ __device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, u
         const rt_f3 e2 = f3(ra[6], ra[7], rb[0]);
         const uint32_t id = __float_as_uint(rb[1]);
         if (STATS && pred) st.tri += 1;
+        if (STATS && (threadIdx.x & 63u) == 0u) st.bytes += 48;
         const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
         if (ANY) {
             if (pred && !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) {
@@ -332,6 +339,10 @@ __device__ __forceinline__ void packet_search(const SceneView& sv, uint32_t root
         if (STATS && active) {
             st.node += 1;
             st.box += 4;
+        }
+        if (STATS && (threadIdx.x & 63u) == 0u) {
+            st.bytes += 128;
+            st.walks[3] += 1;
         }
         float tn0, tn1, tn2, tn3;
         bool h0, h1, h2, h3;
@@ -443,6 +454,9 @@ struct Beam {
 };
 
 #define RT_MARGIN 9.5367431640625e-7f  // 2^-20
+#ifndef RT_ANY_FIRST_PENDING
+#define RT_ANY_FIRST_PENDING 1
+#endif
 #define RT_MAX_SLOPE 8.0f
 
 template <int K>
@@ -531,6 +545,7 @@ __device__ __forceinline__ void beam_node(const SceneView& sv, uint32_t ref, con
     if (STATS && lane == 0) {
         st.node += 1;
         st.box += count;
+        st.bytes += 32 * count;
     }
     if (lane < count) {
         const float4* cp = reinterpret_cast<const float4*>(sv.wide + first + lane);
@@ -566,8 +581,12 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     Beam b;
     BeamLane bl;
     b.sgn = sgn;
-    if (!make_beam<M>(sv, o, d, active, b, bl, true)) return false;
+    if (!make_beam<M>(sv, o, d, active, b, bl, true)) {
+        if (STATS && (threadIdx.x & 63u) == 0u) st.walks[1] += 1;
+        return false;
+    }
     const uint32_t lane = threadIdx.x & 63u;
+    if (STATS && lane == 0) st.walks[0] += 1;
     uint32_t local_best = 0;
     // Farthest useful w per lane, relative to wbase: where the ray's current nearest hit lies.
     auto far_rel = [&](float c) {
@@ -581,7 +600,15 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     uint32_t key, cref;
     beam_node<M, STATS>(sv, root_ref, b, wend_rel, lane, key, cref, st);
     for (;;) {
-        const uint32_t kmin = wave_min_u32(key);
+        uint32_t kmin;
+        if (ANY && RT_ANY_FIRST_PENDING) {
+            // Any occluder will do, so the order of the visits is free: take the first pending lane
+            // (one ballot) instead of the nearest child (a wave-wide minimum).
+            const unsigned long long pm = __ballot(key != 0xFFFFFFFFu);
+            kmin = pm ? (uint32_t)__builtin_ctzll(pm) : 0xFFFFFFFFu;
+        } else {
+            kmin = wave_min_u32(key);
+        }
         const float kf = __uint_as_float(kmin & ~63u);
         // Lanes that can still gain from pending children: all unoccluded lanes in shadow mode;
         // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
@@ -605,6 +632,7 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
             BeamLane tmp;
             make_beam<M>(sv, o, d, active, b, tmp, false);
             n_beam = n_rel;
+            if (STATS && lane == 0) st.walks[2] += 1;
         }
         const uint32_t sel = kmin & 63u;
         const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)sel);
@@ -690,9 +718,12 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
     return h;
 }
 
+// `cell` groups the lanes: when the whole wave does not form a usable beam, the lanes of one
+// cell at a time are tried as a beam of their own (rays sorted by a spatial key share a cell with
+// their neighbours; a wave that straddles two distant cells splits into two thin beams).
 template <bool STATS>
 __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, uint2* beam_lds,
-                                               LaneStats& st) {
+                                               LaneStats& st, uint32_t cell = 0) {
     const rt_f3 inv = g_recip(d);
     if (STATS && active) st.rays += 1;
     bool occluded = false;
@@ -710,8 +741,27 @@ __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_
             float closest = RT_INF;
             HitD dummy;
             bool occ = false;
-            if (!beam_try<true, STATS>(sv, wide_root, oi, o, d, in_obj, closest, dummy, occ, beam_lds, st))
-                packet_search<true, STATS>(sv, root, oi, o, d, inv, in_obj, closest, dummy, occ, st);
+            // First the whole wave as one beam; failing that, one cell's lanes at a time, each as
+            // a beam if it forms one and by the mask walk otherwise.
+            bool todo = in_obj, whole = true;
+            for (;;) {
+                const unsigned long long tm = __ballot(todo);
+                if (tm == 0ull) break;
+                bool grp = todo;
+                if (!whole) {
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, __builtin_ctzll(tm));
+                    grp = todo && cell == c0;
+                }
+                // A group equal to the whole wave has already failed as a beam.
+                const bool same = !whole && __ballot(grp) == __ballot(in_obj);
+                bool done = !same && beam_try<true, STATS>(sv, wide_root, oi, o, d, grp, closest, dummy, occ, beam_lds, st);
+                if (!done && !whole) {
+                    packet_search<true, STATS>(sv, root, oi, o, d, inv, grp, closest, dummy, occ, st);
+                    done = true;
+                }
+                if (done) todo = todo && !grp;
+                whole = false;
+            }
             if (occ) {
                 occluded = true;
                 active = false;
@@ -736,9 +786,9 @@ __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_
 
 __device__ __forceinline__ void flush_stats(const LaneStats& st, DevStats* out) {
     // One atomic per counter per lane would be heavy; reduce over the wave first.
-    unsigned long long v[4] = {st.rays, st.box, st.tri, st.node};
+    unsigned long long v[9] = {st.rays, st.box, st.tri, st.node, st.bytes, st.walks[0], st.walks[1], st.walks[2], st.walks[3]};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 9; ++k) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         v[k] = x;
@@ -748,6 +798,8 @@ __device__ __forceinline__ void flush_stats(const LaneStats& st, DevStats* out) 
         atomicAdd(&out->box_tests, v[1]);
         atomicAdd(&out->tri_tests, v[2]);
         atomicAdd(&out->node_visits, v[3]);
+        atomicAdd(&out->fetch_bytes, v[4]);
+        for (int k = 0; k < 4; ++k) atomicAdd(&out->walks[k], v[5 + k]);
     }
 }
 
@@ -1249,6 +1301,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
         const float qv = fminf(fmaxf((v - lp.v0) * lp.vscale, 0.0f), 65535.0f);
         key = spread16((uint32_t)qu) | (spread16((uint32_t)qv) << 1);
         if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
+        key >>= 32u - lp.key_bits;  // below 32 bits no key can equal the all-ones "no shadow ray" value
     }
     keys[slot] = key;
     vals[slot] = slot;
@@ -1257,6 +1310,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
 
 template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
+                                                        uint32_t cell_shift,
                                                         const uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals,
                                                         const float4* __restrict__ samp, uint32_t* __restrict__ state,
@@ -1272,7 +1326,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView s
     const rt_f3 pos = f3(a.x, a.y, a.z);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
     const rt_f3 sdir = g_normalize(sun - pos);
-    const bool occ = any_all_packet<STATS>(sv, pos, sdir, act, s_beam, st);
+    const bool occ = any_all_packet<STATS>(sv, pos, sdir, act, s_beam, st, act ? keys[i] >> cell_shift : 0u);
     if (act && occ) state[slot] |= RT_ST_OCC;
     if (STATS) flush_stats(st, stats);
 }
@@ -1434,15 +1488,16 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
     return hipGetLastError();
 }
 
-hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, const uint32_t* d_keys,
-                     const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state, DevStats* d_stats, hipStream_t s) {
+hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
+                     const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
+                     DevStats* d_stats, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const size_t lds = (size_t)(RT_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, d_keys,
+        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
                            d_vals, d_samp, d_state, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, d_keys,
+        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
                            d_vals, d_samp, d_state, d_stats);
     return hipGetLastError();
 }

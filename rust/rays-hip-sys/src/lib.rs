@@ -68,6 +68,8 @@ pub struct rt_stats {
     pub primary_box_tests: u64,
     pub primary_tri_tests: u64,
     pub primary_node_visits: u64,
+    pub fetch_bytes: u64,
+    pub primary_fetch_bytes: u64,
 }
 
 extern "C" {
