@@ -254,6 +254,7 @@ __device__ __forceinline__ uint32_t sload1u(const void* p) { return *(const RT_C
 #define RT_INF_BITS 0x7f800000
 #define RT_BALLOT(pred) __ballot(pred)
 
+
 // Wave-shared stack of at most 128 node references: entry i is lane (i & 63) of r0 / r1.
 struct WaveStack {
     int r0 = 0, r1 = 0;
@@ -457,6 +458,9 @@ struct Beam {
 #ifndef RT_ANY_FIRST_PENDING
 #define RT_ANY_FIRST_PENDING 1
 #endif
+#ifndef RT_BEAM_TAILCALL
+#define RT_BEAM_TAILCALL 1
+#endif
 #define RT_MAX_SLOPE 8.0f
 
 template <int K>
@@ -599,7 +603,8 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     int level = 0;
     uint32_t key, cref;
     beam_node<M, STATS>(sv, root_ref, b, wend_rel, lane, key, cref, st);
-    for (;;) {
+    bool running = true;
+    while (running) {
         uint32_t kmin;
         if (ANY && RT_ANY_FIRST_PENDING) {
             // Any occluder will do, so the order of the visits is free: take the first pending lane
@@ -614,42 +619,56 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
         // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
         // walk is front to back along w, so the others are finished for this level).
         const unsigned long long rel = ANY ? __ballot(active) : __ballot(active && zc > kf);
-        if (ANY && rel == 0ull) break;
-        if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
-            if (level == 0) break;
-            --level;
-            const uint2 e = lds[level * 64 + lane];
-            key = e.x;
-            cref = e.y;
-            continue;
-        }
-        // Shadow mode: shrink the beam to the unoccluded lanes once half of them have dropped out;
-        // the children tested from here on are culled against the thinner beam. (An occluded lane
-        // is finished for good. In nearest-hit mode a lane that is finished for this level can
-        // still be needed by a nearer child pending further out, so the beam is kept.)
-        const int n_rel = __builtin_popcountll(rel);
-        if (ANY && 2 * n_rel <= n_beam) {
-            BeamLane tmp;
-            make_beam<M>(sv, o, d, active, b, tmp, false);
-            n_beam = n_rel;
-            if (STATS && lane == 0) st.walks[2] += 1;
-        }
-        const uint32_t sel = kmin & 63u;
-        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)sel);
-        if (lane == sel) key = 0xFFFFFFFFu;
-        if (r & LEAF_BIT) {
-            const float before = closest;
-            packet_leaf<ANY, STATS>(sv, r, obj_index, active, o, d, closest, local_best, hit, active, occluded, st);
-            if (!ANY) {
-                if (__ballot(closest < before) != 0ull) {
-                    zc = far_rel(closest);
-                    wend_rel = wave_max_f32(active ? zc : -RT_INF);
-                }
+        if (ANY && rel == 0ull) {
+            running = false;
+        } else if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
+            // Nothing left at this level: back to the level above.
+            if (level == 0) {
+                running = false;
+            } else {
+                --level;
+                const uint2 e = lds[level * 64 + lane];
+                key = e.x;
+                cref = e.y;
             }
         } else {
-            lds[level * 64 + lane] = make_uint2(key, cref);
-            ++level;
-            beam_node<M, STATS>(sv, r, b, wend_rel, lane, key, cref, st);
+            // Shadow mode: shrink the beam to the unoccluded lanes once half of them have dropped
+            // out; the children tested from here on are culled against the thinner beam. (An
+            // occluded lane is finished for good. In nearest-hit mode a lane that is finished for
+            // this level can still be needed by a nearer child pending further out, so the beam is
+            // kept.)
+            const int n_rel = __builtin_popcountll(rel);
+            if (ANY && 2 * n_rel <= n_beam) {
+                BeamLane tmp;
+                make_beam<M>(sv, o, d, active, b, tmp, false);
+                n_beam = n_rel;
+                if (STATS && lane == 0) st.walks[2] += 1;
+            }
+            const uint32_t sel = kmin & 63u;
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)sel);
+            if (lane == sel) key = 0xFFFFFFFFu;
+            if (r & LEAF_BIT) {
+                const float before = closest;
+                packet_leaf<ANY, STATS>(sv, r, obj_index, active, o, d, closest, local_best, hit, active, occluded, st);
+                if (!ANY) {
+                    if (__ballot(closest < before) != 0ull) {
+                        zc = far_rel(closest);
+                        wend_rel = wave_max_f32(active ? zc : -RT_INF);
+                    }
+                }
+            } else {
+#if RT_BEAM_TAILCALL
+                // The level's remaining children are kept only if there are any.
+                if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
+                    lds[level * 64 + lane] = make_uint2(key, cref);
+                    ++level;
+                }
+#else
+                lds[level * 64 + lane] = make_uint2(key, cref);
+                ++level;
+#endif
+                beam_node<M, STATS>(sv, r, b, wend_rel, lane, key, cref, st);
+            }
         }
     }
     return true;
@@ -1267,6 +1286,11 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v) {
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 8
 #endif
+// Workgroup size of the camera- and shadow-ray kernels. Their waves do not cooperate, so a small
+// group only changes how soon a finished wave's slot is handed to the next group.
+#ifndef RT_WF_BLOCK
+#define RT_WF_BLOCK 64
+#endif
 template <bool STATS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv, DevRenderParams p, LightProj lp,
                                                       const uint32_t* __restrict__ tile_list,
@@ -1309,7 +1333,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
+__global__ __launch_bounds__(RT_WF_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
                                                         uint32_t cell_shift,
                                                         const uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals,
@@ -1317,7 +1341,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView s
                                                         DevStats* __restrict__ stats) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * RT_WF_BLOCK + threadIdx.x;
     const bool act = i < n && keys[i] != 0xFFFFFFFFu;
     if (__ballot(act) == 0ull) return;  // keys are sorted: samples without a shadow ray come last
     LaneStats st;
@@ -1476,14 +1500,14 @@ hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t*
 hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
                       float4* d_samp, uint32_t* d_state, uint32_t* d_keys, uint32_t* d_vals, DevStats* d_stats,
                       hipStream_t s) {
-    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
+    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_WF_BLOCK / p.spp));
     if (blocks == 0) return hipSuccess;
-    const size_t lds = (size_t)(RT_BLOCK / 64) * p.beam_levels * 64 * 8;
+    const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_primary<true, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), lds, s, sv, p, lp, d_tile_list,
+        hipLaunchKernelGGL((k_wf_primary<true, RT_WF_BLOCK>), dim3(blocks), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_vals, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_primary<false, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), lds, s, sv, p, lp, d_tile_list,
+        hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(blocks), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_vals, d_stats);
     return hipGetLastError();
 }
@@ -1492,12 +1516,12 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
                      DevStats* d_stats, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    const size_t lds = (size_t)(RT_BLOCK / 64) * p.beam_levels * 64 * 8;
+    const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
+        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid_for(n, RT_WF_BLOCK)), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
                            d_vals, d_samp, d_state, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
+        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid_for(n, RT_WF_BLOCK)), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
                            d_vals, d_samp, d_state, d_stats);
     return hipGetLastError();
 }
