@@ -30,7 +30,7 @@ FLOP_BOX, FLOP_TRI = 18, 46          # per slab test / per triangle test
 BYTES_BOX, BYTES_TRI = 32, 36        # structure bytes per slab test / per triangle test
 
 
-def cpu_baseline(objects, width, height, target_seconds=15.0):
+def cpu_baseline(objects, width, height, target_seconds=20.0):
     """Times the CPU oracle (a C++ restatement of the reference's linear packet scan, AVX2/FMA)
     on a strided pixel subsample of the same frame. Reported next to the GPU number; never part
     of the measured path."""

@@ -1235,17 +1235,42 @@ __global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams 
 #define RT_ST_LIT 2u
 #define RT_ST_OCC 4u
 
+// Workgroups are handed to the eight XCDs in turn, and each XCD has its own L2. The groups are
+// renumbered so that runs of RT_XCD_GROUP consecutive work items (neighbouring rays, which walk the
+// same part of the tree) go to one XCD. The launch is padded to a multiple of 8 * RT_XCD_GROUP
+// groups; renumbered groups at or beyond the real count have nothing to do.
+#ifndef RT_XCD_GROUP
+#define RT_XCD_GROUP 64
+#endif
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b) {
+#if RT_XCD_GROUP > 0
+    const uint32_t x = b & 7u, j = b >> 3;
+    return ((j / RT_XCD_GROUP) * 8u + x) * RT_XCD_GROUP + j % RT_XCD_GROUP;
+#else
+    return b;
+#endif
+}
+static inline uint32_t xcd_grid(uint32_t blocks) {
+#if RT_XCD_GROUP > 0
+    const uint32_t unit = 8u * RT_XCD_GROUP;
+    return (blocks + unit - 1) / unit * unit;
+#else
+    return blocks;
+#endif
+}
+
 template <int BLOCK>
 struct PixelMap {
-    uint32_t x, y, s, mx, my, local_tile;
+    uint32_t x, y, s, mx, my, local_tile, block;
     bool inside;
-    __device__ __forceinline__ PixelMap(const DevRenderParams& p, const uint32_t* tile_list) {
+    __device__ __forceinline__ PixelMap(const DevRenderParams& p, const uint32_t* tile_list, bool remap = false) {
         const uint32_t spp = p.spp;
         const uint32_t ppb = BLOCK / spp;
         const uint32_t blocks_per_tile = (RT_TILE * RT_TILE) / ppb;
-        local_tile = blockIdx.x / blocks_per_tile;
-        const uint32_t block_in_tile = blockIdx.x % blocks_per_tile;
-        const uint32_t tile = tile_list ? tile_list[local_tile] : local_tile;
+        block = remap ? xcd_block(blockIdx.x) : blockIdx.x;
+        local_tile = block / blocks_per_tile;
+        const uint32_t block_in_tile = block % blocks_per_tile;
+        const uint32_t tile = (tile_list && local_tile < p.n_tiles) ? tile_list[local_tile] : local_tile;
         const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
         s = threadIdx.x % spp;
         const uint32_t pix_in_tile = block_in_tile * ppb + threadIdx.x / spp;
@@ -1299,7 +1324,8 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
                                                       DevStats* __restrict__ stats) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
-    const PixelMap<BLOCK> pm(p, tile_list);
+    const PixelMap<BLOCK> pm(p, tile_list, true);
+    if (pm.local_tile >= p.n_tiles) return;  // padding of the renumbered launch
     LaneStats st;
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
@@ -1310,7 +1336,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     const Surface sf = surface_of(sv, hs, o, d);
     const rt_f3 sun_dir = g_normalize(sun - sf.pos);
     const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t slot = pm.block * BLOCK + threadIdx.x;
     samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(h.tri));
     state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
     // Light-space key: the hit point projected from the sun onto the plane across the light's
@@ -1341,7 +1367,7 @@ __global__ __launch_bounds__(RT_WF_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneVie
                                                         DevStats* __restrict__ stats) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
-    const uint32_t i = blockIdx.x * RT_WF_BLOCK + threadIdx.x;
+    const uint64_t i = (uint64_t)xcd_block(blockIdx.x) * RT_WF_BLOCK + threadIdx.x;
     const bool act = i < n && keys[i] != 0xFFFFFFFFu;
     if (__ballot(act) == 0ull) return;  // keys are sorted: samples without a shadow ray come last
     LaneStats st;
@@ -1504,10 +1530,10 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
     if (blocks == 0) return hipSuccess;
     const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_primary<true, RT_WF_BLOCK>), dim3(blocks), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
+        hipLaunchKernelGGL((k_wf_primary<true, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_vals, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(blocks), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
+        hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_vals, d_stats);
     return hipGetLastError();
 }
@@ -1518,10 +1544,10 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
     if (n == 0) return hipSuccess;
     const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid_for(n, RT_WF_BLOCK)), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
+        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(xcd_grid(grid_for(n, RT_WF_BLOCK))), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
                            d_vals, d_samp, d_state, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid_for(n, RT_WF_BLOCK)), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
+        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(xcd_grid(grid_for(n, RT_WF_BLOCK))), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
                            d_vals, d_samp, d_state, d_stats);
     return hipGetLastError();
 }
