@@ -86,14 +86,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N > 1 needs torch.distributed.run with N processes")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RAYS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
+    # share the visible GPUs and the per-frame gather is staged through host memory. Never a result.
+    backend = os.environ.get("RAYS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W, H = args.width, args.height
     objects = scenes.soup(args.tris, args.seed)
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     t0 = time.perf_counter()
     scene = Scene(ctx, objects)
     build_s = time.perf_counter() - t0
@@ -117,7 +124,8 @@ def main():
 
     # Counters of one frame from the instrumented build (not timed).
     st = scene.render_device_stats(p, frames[0].data_ptr())
-    counts = torch.tensor([st["rays"], st["box_tests"], st["tri_tests"]], dtype=torch.int64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    counts = torch.tensor([st["rays"], st["box_tests"], st["tri_tests"]], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
     rays_total, box_total, tri_total = [int(x) for x in counts.tolist()]
@@ -157,7 +165,11 @@ def main():
         render_done[b].record(stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
-            gathered, _ = rd.gather_slabs(frames[b], slab_bytes, dst=0)
+            if backend == "nccl":
+                gathered, _ = rd.gather_slabs(frames[b], slab_bytes, dst=0)
+            else:
+                host, _ = rd.gather_slabs(frames[b].cpu(), slab_bytes, dst=0)
+                gathered = host.to(dev) if rank == 0 else None
             if rank == 0:
                 ctx.deinterleave_device(gathered.data_ptr(), slab, W, H, world, full.data_ptr(),
                                         comm_stream.cuda_stream)
@@ -178,10 +190,19 @@ def main():
         step(args.warmup + i, i)
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # Self-check of the sharded path (not timed): the frame rank 0 assembled from the ranks' tiles
+    # must equal the same frame rendered whole on rank 0's GPU.
+    frame_ok = None
+    if world > 1 and rank == 0:
+        whole = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+        p1 = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0)
+        scene.render_device(p1, whole.data_ptr(), None, sh)
+        torch.cuda.synchronize()
+        frame_ok = bool(torch.equal(whole, full))
     phase_ms = [float(np.mean([elapsed_ms(ev[k], ev[k + 1]) for ev in phase_events])) for k in range(4)]
     kernel_ms = phase_ms[0]  # the camera-ray kernel, the longest of the frame
 
@@ -235,6 +256,8 @@ def main():
                              "resolve": phase_ms[3]},
                 "scene_build_s": build_s,
                 "parallelism": f"tiles{world}" if world > 1 else "single",
+                "sharded_frame_equals_whole_frame": frame_ok,
+                "backend": backend if world > 1 else None,
             },
             "roofline": {
                 "bound": "hbm",

@@ -252,13 +252,14 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // Only the leading bits of the interleaved key are kept and sorted: the sort is stable, so the
     // rays of one cell keep their screen order, which is coherent enough within a cell of a few
     // hundred rays, and each 8 bits less saves one pass over the pairs. Key bits = log2(n / 512)
-    // rounded up to an even number, at least 8.
+    // rounded up to an even number, at least 16: a cell must stay narrower than the widest beam the
+    // walk accepts (1/128 of the scene) or the waves stop forming beams.
     {
         static const long env_bits = [] {
             const char* e = std::getenv("RAYS_HIP_SORT_BITS");
             return e ? std::atol(e) : 0L;
         }();
-        uint32_t kb = 8;
+        uint32_t kb = 16;
         while (kb < 32 && ((size_t)512 << kb) < n_slots) kb += 2;
         if (env_bits >= 2 && env_bits <= 32) kb = (uint32_t)env_bits & ~1u;
         lp.key_bits = kb;
