@@ -210,17 +210,19 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total * args.steps / elapsed / 1e6
         # Roofline of the dominant kernel, the camera-ray kernel (k_wf_primary), per launch.
-        # Algorithmic bytes = what the launch has to move: 28 B written per sample (hit point + id
-        # 16 B, state 4 B, sort key 4 B, sort value 4 B; camera rays are generated on the device,
-        # 0 B in) + the tree-node and triangle-record bytes its loads request (32 B per child box
-        # tested, 48 B per triangle record; a load that serves a whole wave counts once), from the
-        # kernel's own counters in the instrumented build. The tests-per-ray formula
-        # 32 B * box tests + 36 B * triangle tests is kept beside it as "per_ray_structure_bytes":
-        # it prices every ray's test as if the ray had fetched its operands itself.
+        # Algorithmic bytes = what one launch has to move to and from HBM: 28 B written per sample
+        # (hit point + id 16 B, state 4 B, sort key 4 B, sort value 4 B; camera rays are generated
+        # on the device, 0 B in) + the wide tree, the triangle records and the normals/colours read
+        # once (they fit in L2 / Infinity Cache, so a launch needs them from HBM at most once).
+        # "requested_bytes_per_launch" is what the kernel's loads ask the caches for (32 B per child
+        # box a wave tests + 48 B per triangle record a wave fetches, from the kernel's own counters
+        # in the instrumented build): per-ray structure bytes at the granularity the loads are
+        # issued. Its ratio to `traffic` is the cache amplification.
         my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
         n_samples_rank = st["primary_rays"]
-        alg_bytes = 28 * n_samples_rank + st["primary_fetch_bytes"]
-        per_ray_structure_bytes = BYTES_BOX * my_box + BYTES_TRI * my_tri
+        sizes = scene.sizes()
+        alg_bytes = 28 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
+        requested_bytes = 28 * n_samples_rank + st["primary_fetch_bytes"]
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (collected with
@@ -269,7 +271,8 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": kernel_ms,
                 "alg_bytes_per_launch": alg_bytes,
-                "per_ray_structure_bytes": per_ray_structure_bytes,
+                "requested_bytes_per_launch": requested_bytes,
+                "requested_tb_per_s": requested_bytes / (kernel_ms * 1e-3) / 1e12,
                 "valu_tflops": alg_flops / (kernel_ms * 1e-3) / 1e12,
                 "valu_frac": alg_flops / (kernel_ms * 1e-3) / FP32_PEAK,
             },

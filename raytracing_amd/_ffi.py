@@ -78,6 +78,7 @@ SYMBOLS = {
     "rt_scene_build": (C.c_int, [_VP, C.POINTER(rt_object_desc), C.c_uint32, C.POINTER(_VP)]),
     "rt_scene_destroy": (None, [_VP]),
     "rt_scene_num_tris": (C.c_uint32, [_VP]),
+    "rt_scene_sizes": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "rt_scene_order": (C.c_int, [_VP, C.c_uint32, _VP]),
     "rt_scene_packed": (C.c_int, [_VP, C.c_uint32, _VP, _VP]),
     "rt_trace_closest": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
@@ -232,6 +233,12 @@ class Scene:
     @property
     def num_tris(self):
         return self.lib.rt_scene_num_tris(self.handle)
+
+    def sizes(self):
+        """Device bytes of the scene's arrays: wide tree, 4-wide tree, triangle records, tri_data."""
+        out = (C.c_uint64 * 4)()
+        check(self.lib.rt_scene_sizes(self.handle, out))
+        return dict(zip(("wide", "nodes4", "recs", "tri_data"), [int(x) for x in out]))
 
     def order(self, obj):
         out = np.empty(self.obj_tris[obj], dtype=np.uint32)

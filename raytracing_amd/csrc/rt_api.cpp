@@ -119,6 +119,7 @@ struct rt_scene {
     uint32_t n_tris = 0;
     uint32_t n_leaves = 0;
     uint32_t n_nodes = 0;
+    uint64_t sizes[4] = {0, 0, 0, 0};  // device bytes: wide tree, 4-wide tree, triangle records, tri_data
     uint32_t max_stack = 0;
     uint32_t wide_depth = 1;
     std::vector<DevObject> objects;
@@ -447,7 +448,7 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
     std::vector<rtbvh::Child> wide_all;
     std::vector<uint32_t> order_all;  // record -> global triangle id
     const int nt = host_threads();
-    uint32_t wide_width = 32;
+    uint32_t wide_width = 64;
     if (const char* e = std::getenv("RAYS_HIP_WIDE")) wide_width = (uint32_t)std::atoi(e);
     for (uint32_t o = 0; o < n_objs; ++o) {
         DevObject& ob = s->objects[o];
@@ -482,6 +483,10 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         for (uint32_t r : res.order) order_all.push_back(ob.tri_base + r);
     }
     s->n_nodes = (uint32_t)nodes_all.size();
+    s->sizes[0] = wide_all.size() * sizeof(rtbvh::Child);
+    s->sizes[1] = nodes_all.size() * sizeof(rtbvh::Node4);
+    s->sizes[2] = order_all.size() * 48;
+    s->sizes[3] = (uint64_t)s->n_tris * 24;
     {
         bool any_tree = false;
         for (const DevObject& ob : s->objects) any_tree = any_tree || ob.root != rtbvh::EMPTY;
@@ -569,6 +574,12 @@ void rt_scene_destroy(rt_scene* s) {
 }
 
 uint32_t rt_scene_num_tris(const rt_scene* s) { return s ? s->n_tris : 0; }
+
+int rt_scene_sizes(const rt_scene* s, uint64_t sizes[4]) {
+    if (!s || !sizes) return fail(RT_ERR_INVALID, "null argument");
+    for (int k = 0; k < 4; ++k) sizes[k] = s->sizes[k];
+    return RT_OK;
+}
 
 int rt_scene_order(const rt_scene* s, uint32_t obj, uint32_t* order) {
     if (!s || !order) return fail(RT_ERR_INVALID, "null argument");

@@ -78,6 +78,7 @@ extern "C" {
     pub fn rt_scene_build(ctx: *mut rt_ctx, objs: *const rt_object_desc, n_objs: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
     pub fn rt_scene_num_tris(scene: *const rt_scene) -> u32;
+    pub fn rt_scene_sizes(scene: *const rt_scene, sizes: *mut u64) -> c_int;
     pub fn rt_scene_order(scene: *const rt_scene, obj: u32, order: *mut u32) -> c_int;
     pub fn rt_scene_packed(scene: *const rt_scene, obj: u32, tris9: *mut f32, leaf_bounds6: *mut f32) -> c_int;
     pub fn rt_trace_closest(scene: *mut rt_scene, rays: *const rt_ray, n: u64, out: *mut rt_hit) -> c_int;

@@ -286,6 +286,63 @@ def test_device_entry_points_match_host_entry_points(teapot_pair):
     assert st["rays"] >= 160 * 90 * 4 and st["tri_tests"] > 0 and st["box_tests"] > 0
 
 
+def test_render_events_stats_and_sizes(soup_pair):
+    """rt_render_device_events records its five events in order on the caller's stream and renders
+    the same frame as rt_render; rt_render_device_stats counts every search once; rt_scene_sizes
+    reports the arrays the counters refer to."""
+    import ctypes
+
+    import torch
+
+    g, _ = soup_pair
+    W, H = 320, 200
+    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1)
+    ref, ids = g.render(p, want_hit_ids=True)
+    hip = ctypes.CDLL("libamdhip64.so")
+    evs = []
+    for _ in range(5):
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        evs.append(e)
+    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        g.render_device_events(p, frame.data_ptr(), [e.value for e in evs], None, stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), ref)
+    for k in range(4):
+        ms = ctypes.c_float()
+        assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[k], evs[k + 1]) == 0
+        assert ms.value >= 0.0
+    for e in evs:
+        hip.hipEventDestroy(e)
+    with pytest.raises(Exception):
+        g.render_device_events(p, frame.data_ptr(), [0] * 5, None, stream.cuda_stream)
+
+    st = g.render_device_stats(p, frame.data_ptr())
+    n = W * H * 4
+    assert st["primary_rays"] == n
+    assert n <= st["rays"] <= 2 * n                       # at most one shadow ray per sample
+    assert st["primary_tri_tests"] <= st["tri_tests"] and st["primary_box_tests"] <= st["box_tests"]
+    assert 0 < st["primary_fetch_bytes"] <= st["fetch_bytes"]
+    assert st["rays"] - n <= int((ids != RT_MISS).sum())   # only hits cast shadow rays
+    assert np.array_equal(frame.cpu().numpy(), ref)        # the instrumented build renders the same frame
+    sz = g.sizes()
+    assert sz["recs"] == 48 * g.num_tris and sz["tri_data"] == 24 * g.num_tris
+    assert sz["wide"] % 32 == 0 and sz["wide"] >= 32 * g.num_tris // 4 and sz["nodes4"] % 128 == 0
+
+
+@pytest.mark.parametrize("size", [(96, 64), (352, 200), (1000, 560)])
+def test_render_soup_frame_sizes_cover_every_sort_path(soup_pair, size):
+    """Frame sizes whose shadow-ray sorts fall into the small, middle and large size classes of the
+    radix sort, with tile counts that are not a multiple of the launch padding."""
+    g, o = soup_pair
+    W, H = size
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, reflect_depth=1, diffuse_depth=1, want_hit_ids=True)
+    rgba, ids = g.render(render_params(W, H, 2, reflect_depth=1, diffuse_depth=1), want_hit_ids=True)
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
+
+
 def test_full_size_properties_soup_1m(ctx, oracle):
     """BASELINE configuration 3 at full size: 1,000,000 triangles, 3840x2160, four samples. The
     oracle cannot scan it in full in test time, so: a strided subsample is compared ray by ray, the
