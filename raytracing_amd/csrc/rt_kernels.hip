@@ -452,11 +452,18 @@ struct Beam {
     float a0[2], a1[2], b0[2], b1[2];  // over the lateral axes (M+1)%3... see lat_axis
     float wbase;      // w of the first origin when the walk started: keys are w - wbase
     float wstart;     // smallest origin w among the lanes the beam covers
+    float wfar;       // largest origin w among them
 };
 
 #define RT_MARGIN 9.5367431640625e-7f  // 2^-20
 #ifndef RT_ANY_FIRST_PENDING
 #define RT_ANY_FIRST_PENDING 1
+#endif
+#ifndef RT_ANY_PREFER_FAR
+#define RT_ANY_PREFER_FAR 1
+#endif
+#ifndef RT_LEAVES_AT_ONCE
+#define RT_LEAVES_AT_ONCE 1
 #endif
 #ifndef RT_BEAM_TAILCALL
 #define RT_BEAM_TAILCALL 1
@@ -524,6 +531,9 @@ __device__ __forceinline__ bool make_beam(const SceneView& sv, rt_f3 o, rt_f3 d,
     }
     const float ws = wave_min_f32(active ? bl.ow : RT_INF);
     b.wstart = ws - __builtin_fabsf(ws) * RT_MARGIN;
+#if RT_ANY_PREFER_FAR
+    b.wfar = wave_max_f32(active ? bl.ow : -RT_INF);
+#endif
     if (first) b.wbase = b.wstart;
     // A beam much wider than the geometry it meets makes every lane test every triangle of a
     // large region (rays that happen to share a wave but not a neighbourhood): leave those waves
@@ -540,7 +550,7 @@ __device__ __forceinline__ bool make_beam(const SceneView& sv, rt_f3 o, rt_f3 d,
 // and wend_rel (the farthest w, relative to wbase, at which any ray can still gain a hit).
 // key = entry w relative to wbase with the lane number in its low six bits (0xFFFFFFFF: no
 // visit), cref = the child's reference.
-template <int M, bool STATS>
+template <int M, bool STATS, bool ANYMODE = false>
 __device__ __forceinline__ void beam_node(const SceneView& sv, uint32_t ref, const Beam& b, float wend_rel,
                                           uint32_t lane, uint32_t& key, uint32_t& cref, LaneStats& st) {
     const uint32_t first = ref >> 6, count = (ref & 63u) + 1u;
@@ -572,6 +582,11 @@ __device__ __forceinline__ void beam_node(const SceneView& sv, uint32_t ref, con
             hit = hit & (blo <= comp<lat_axis<M, 1>::value>(hi)) & (bhi >= comp<lat_axis<M, 1>::value>(lo));
         }
         key = hit ? ((__float_as_uint(fmaxf(z0 - b.wbase, 0.0f)) & ~63u) | lane) : 0xFFFFFFFFu;
+#if RT_ANY_PREFER_FAR
+        // Shadow mode reads the key only as "pending" (any value but all ones) and "preferred" (0):
+        // a child that starts beyond every origin can occlude every ray of the wave.
+        if (ANYMODE) key = hit ? (((b.sgn > 0.0f ? lm : -hm) >= b.wfar) ? 0u : 1u) : 0xFFFFFFFFu;
+#endif
         cref = __float_as_uint(B.z);
     }
 }
@@ -601,8 +616,100 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     float wend_rel = ANY ? RT_INF : wave_max_f32(active ? zc : -RT_INF);
     int n_beam = __builtin_popcountll(__ballot(active));  // lanes the current beam was built from
     int level = 0;
-    uint32_t key, cref;
-    beam_node<M, STATS>(sv, root_ref, b, wend_rel, lane, key, cref, st);
+    uint32_t key = 0xFFFFFFFFu, cref = 0;
+#if RT_LEAVES_AT_ONCE
+    // `expand` is the inner node to open next. Its children are tested against the beam, its leaf
+    // children are tested against the rays at once (in lane order: the result does not depend on
+    // the order, and a leaf costs far less this way than as one more turn of the ordered walk),
+    // its inner children become the pending set of a new level.
+    uint32_t expand = root_ref;
+    bool running = true;
+    while (running) {
+        if (expand != 0xFFFFFFFFu) {
+            // The level's remaining children are kept only if there are any.
+            if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
+                lds[level * 64 + lane] = make_uint2(key, cref);
+                ++level;
+            }
+            beam_node<M, STATS, ANY>(sv, expand, b, wend_rel, lane, key, cref, st);
+            expand = 0xFFFFFFFFu;
+            const bool leaf_child = (cref & LEAF_BIT) != 0u;
+            unsigned long long lm = __ballot(key != 0xFFFFFFFFu && leaf_child);
+            bool improved = false;
+            while (lm != 0ull) {
+                const int l = __builtin_ctzll(lm);
+                lm &= lm - 1ull;
+                if (ANY) {
+                    if (__ballot(active) == 0ull) break;
+                } else {
+                    const float kf = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)key, l) & ~63u);
+                    if (__ballot(active && zc > kf) == 0ull) continue;
+                }
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)cref, l);
+                const float before = closest;
+                packet_leaf<ANY, STATS>(sv, r, obj_index, active, o, d, closest, local_best, hit, active, occluded, st);
+                if (!ANY) {
+                    if (__ballot(closest < before) != 0ull) {
+                        zc = far_rel(closest);
+                        improved = true;
+                    }
+                }
+            }
+            if (leaf_child) key = 0xFFFFFFFFu;
+            if (!ANY && improved) wend_rel = wave_max_f32(active ? zc : -RT_INF);
+        }
+        uint32_t kmin;
+        if (ANY && RT_ANY_FIRST_PENDING) {
+            // Any occluder will do, so the order of the visits is free: take the first pending lane
+            // (one ballot) instead of the nearest child (a wave-wide minimum); children that start
+            // beyond every origin first.
+            const unsigned long long pm = __ballot(key != 0xFFFFFFFFu);
+#if RT_ANY_PREFER_FAR
+            const unsigned long long pp = __ballot(key == 0u);
+            kmin = pm ? (uint32_t)__builtin_ctzll(pp ? pp : pm) : 0xFFFFFFFFu;
+#else
+            kmin = pm ? (uint32_t)__builtin_ctzll(pm) : 0xFFFFFFFFu;
+#endif
+        } else {
+            kmin = wave_min_u32(key);
+        }
+        const float kf = __uint_as_float(kmin & ~63u);
+        // Lanes that can still gain from pending children: all unoccluded lanes in shadow mode;
+        // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
+        // walk is front to back along w, so the others are finished for this level).
+        const unsigned long long rel = ANY ? __ballot(active) : __ballot(active && zc > kf);
+        if (ANY && rel == 0ull) {
+            running = false;
+        } else if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
+            // Nothing left at this level: back to the level above.
+            if (level == 0) {
+                running = false;
+            } else {
+                --level;
+                const uint2 e = lds[level * 64 + lane];
+                key = e.x;
+                cref = e.y;
+            }
+        } else {
+            // Shadow mode: shrink the beam to the unoccluded lanes once half of them have dropped
+            // out; the children tested from here on are culled against the thinner beam. (An
+            // occluded lane is finished for good. In nearest-hit mode a lane that is finished for
+            // this level can still be needed by a nearer child pending further out, so the beam is
+            // kept.)
+            const int n_rel = __builtin_popcountll(rel);
+            if (ANY && 2 * n_rel <= n_beam) {
+                BeamLane tmp;
+                make_beam<M>(sv, o, d, active, b, tmp, false);
+                n_beam = n_rel;
+                if (STATS && lane == 0) st.walks[2] += 1;
+            }
+            const uint32_t sel = kmin & 63u;
+            expand = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)sel);
+            if (lane == sel) key = 0xFFFFFFFFu;
+        }
+    }
+#else
+    beam_node<M, STATS, ANY>(sv, root_ref, b, wend_rel, lane, key, cref, st);
     bool running = true;
     while (running) {
         uint32_t kmin;
@@ -610,7 +717,12 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
             // Any occluder will do, so the order of the visits is free: take the first pending lane
             // (one ballot) instead of the nearest child (a wave-wide minimum).
             const unsigned long long pm = __ballot(key != 0xFFFFFFFFu);
+#if RT_ANY_PREFER_FAR
+            const unsigned long long pp = __ballot(key == 0u);
+            kmin = pm ? (uint32_t)__builtin_ctzll(pp ? pp : pm) : 0xFFFFFFFFu;
+#else
             kmin = pm ? (uint32_t)__builtin_ctzll(pm) : 0xFFFFFFFFu;
+#endif
         } else {
             kmin = wave_min_u32(key);
         }
@@ -667,10 +779,11 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
                 lds[level * 64 + lane] = make_uint2(key, cref);
                 ++level;
 #endif
-                beam_node<M, STATS>(sv, r, b, wend_rel, lane, key, cref, st);
+                beam_node<M, STATS, ANY>(sv, r, b, wend_rel, lane, key, cref, st);
             }
         }
     }
+#endif
     return true;
 }
 
