@@ -280,17 +280,12 @@ struct WaveStack {
         (cb) = tc_;               \
     }
 
-// One leaf (wave-uniform reference) against every lane with `pred` set.
+// One triangle record (wave-uniform, in scalar registers) against every lane with `pred` set.
 template <bool ANY, bool STATS>
-__device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, uint32_t obj_index, bool pred, rt_f3 o,
-                                            rt_f3 d, float& closest, uint32_t& local_best, HitD& hit, bool& active,
-                                            bool& occluded, LaneStats& st) {
-    const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
-    const uint32_t n = (ref & 7u) + 1u;
-    for (uint32_t i = 0; i < n; ++i) {
-        const char* rp = reinterpret_cast<const char*>(sv.recs) + 48 * (size_t)(first + i);
-        const f32x8_t ra = sload8(rp);
-        const f32x4_t rb = sload4(rp + 32);
+__device__ __forceinline__ void packet_tri(const f32x8_t ra, const f32x4_t rb, uint32_t obj_index, bool& pred, rt_f3 o,
+                                           rt_f3 d, float& closest, uint32_t& local_best, HitD& hit, bool& active,
+                                           bool& occluded, LaneStats& st) {
+    {
         const rt_f3 v0 = f3(ra[0], ra[1], ra[2]);
         const rt_f3 e1 = f3(ra[3], ra[4], ra[5]);
         const rt_f3 e2 = f3(ra[6], ra[7], rb[0]);
@@ -316,6 +311,27 @@ __device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, u
                 hit.v = ev.v;
             }
         }
+    }
+}
+
+// One leaf (wave-uniform reference) against every lane with `pred` set. With `preloaded`, ra0 / rb0
+// hold the leaf's first record already.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, uint32_t obj_index, bool pred, rt_f3 o,
+                                            rt_f3 d, float& closest, uint32_t& local_best, HitD& hit, bool& active,
+                                            bool& occluded, LaneStats& st, bool preloaded = false,
+                                            f32x8_t ra0 = f32x8_t{}, f32x4_t rb0 = f32x4_t{}) {
+    const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
+    const uint32_t n = (ref & 7u) + 1u;
+    for (uint32_t i = 0; i < n; ++i) {
+        f32x8_t ra = ra0;
+        f32x4_t rb = rb0;
+        if (!(preloaded && i == 0)) {
+            const char* rp = reinterpret_cast<const char*>(sv.recs) + 48 * (size_t)(first + i);
+            ra = sload8(rp);
+            rb = sload4(rp + 32);
+        }
+        packet_tri<ANY, STATS>(ra, rb, obj_index, pred, o, d, closest, local_best, hit, active, occluded, st);
     }
 }
 
@@ -461,12 +477,6 @@ struct Beam {
 #endif
 #ifndef RT_ANY_PREFER_FAR
 #define RT_ANY_PREFER_FAR 1
-#endif
-#ifndef RT_LEAVES_AT_ONCE
-#define RT_LEAVES_AT_ONCE 1
-#endif
-#ifndef RT_BEAM_TAILCALL
-#define RT_BEAM_TAILCALL 1
 #endif
 #define RT_MAX_SLOPE 8.0f
 
@@ -617,7 +627,6 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     int n_beam = __builtin_popcountll(__ballot(active));  // lanes the current beam was built from
     int level = 0;
     uint32_t key = 0xFFFFFFFFu, cref = 0;
-#if RT_LEAVES_AT_ONCE
     // `expand` is the inner node to open next. Its children are tested against the beam, its leaf
     // children are tested against the rays at once (in lane order: the result does not depend on
     // the order, and a leaf costs far less this way than as one more turn of the ordered walk),
@@ -708,82 +717,6 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
             if (lane == sel) key = 0xFFFFFFFFu;
         }
     }
-#else
-    beam_node<M, STATS, ANY>(sv, root_ref, b, wend_rel, lane, key, cref, st);
-    bool running = true;
-    while (running) {
-        uint32_t kmin;
-        if (ANY && RT_ANY_FIRST_PENDING) {
-            // Any occluder will do, so the order of the visits is free: take the first pending lane
-            // (one ballot) instead of the nearest child (a wave-wide minimum).
-            const unsigned long long pm = __ballot(key != 0xFFFFFFFFu);
-#if RT_ANY_PREFER_FAR
-            const unsigned long long pp = __ballot(key == 0u);
-            kmin = pm ? (uint32_t)__builtin_ctzll(pp ? pp : pm) : 0xFFFFFFFFu;
-#else
-            kmin = pm ? (uint32_t)__builtin_ctzll(pm) : 0xFFFFFFFFu;
-#endif
-        } else {
-            kmin = wave_min_u32(key);
-        }
-        const float kf = __uint_as_float(kmin & ~63u);
-        // Lanes that can still gain from pending children: all unoccluded lanes in shadow mode;
-        // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
-        // walk is front to back along w, so the others are finished for this level).
-        const unsigned long long rel = ANY ? __ballot(active) : __ballot(active && zc > kf);
-        if (ANY && rel == 0ull) {
-            running = false;
-        } else if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
-            // Nothing left at this level: back to the level above.
-            if (level == 0) {
-                running = false;
-            } else {
-                --level;
-                const uint2 e = lds[level * 64 + lane];
-                key = e.x;
-                cref = e.y;
-            }
-        } else {
-            // Shadow mode: shrink the beam to the unoccluded lanes once half of them have dropped
-            // out; the children tested from here on are culled against the thinner beam. (An
-            // occluded lane is finished for good. In nearest-hit mode a lane that is finished for
-            // this level can still be needed by a nearer child pending further out, so the beam is
-            // kept.)
-            const int n_rel = __builtin_popcountll(rel);
-            if (ANY && 2 * n_rel <= n_beam) {
-                BeamLane tmp;
-                make_beam<M>(sv, o, d, active, b, tmp, false);
-                n_beam = n_rel;
-                if (STATS && lane == 0) st.walks[2] += 1;
-            }
-            const uint32_t sel = kmin & 63u;
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)sel);
-            if (lane == sel) key = 0xFFFFFFFFu;
-            if (r & LEAF_BIT) {
-                const float before = closest;
-                packet_leaf<ANY, STATS>(sv, r, obj_index, active, o, d, closest, local_best, hit, active, occluded, st);
-                if (!ANY) {
-                    if (__ballot(closest < before) != 0ull) {
-                        zc = far_rel(closest);
-                        wend_rel = wave_max_f32(active ? zc : -RT_INF);
-                    }
-                }
-            } else {
-#if RT_BEAM_TAILCALL
-                // The level's remaining children are kept only if there are any.
-                if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
-                    lds[level * 64 + lane] = make_uint2(key, cref);
-                    ++level;
-                }
-#else
-                lds[level * 64 + lane] = make_uint2(key, cref);
-                ++level;
-#endif
-                beam_node<M, STATS, ANY>(sv, r, b, wend_rel, lane, key, cref, st);
-            }
-        }
-    }
-#endif
     return true;
 }
 
