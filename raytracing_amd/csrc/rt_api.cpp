@@ -112,7 +112,8 @@ struct FrameWork {
 
 struct rt_scene {
     rt_ctx* ctx = nullptr;
-    FrameWork work;
+    FrameWork work;         // per sample: camera rays and their shadow rays
+    FrameWork bounce_work;  // per scatter ray of a run of tiles
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
     SceneView view{};
     std::vector<void*> device_ptrs;
@@ -126,6 +127,7 @@ struct rt_scene {
     std::vector<std::vector<uint32_t>> order;  // per object: sorted position -> input position
     ~rt_scene() {
         work.release();
+        bounce_work.release();
         for (void* p : device_ptrs) (void)hipFree(p);
     }
 };
@@ -177,6 +179,77 @@ int check_render_params(const rt_render_params* p, uint32_t* spp) {
     return RT_OK;
 }
 
+// Per-sample (or per-ray) arrays of the kernel pipeline, grown on demand and kept with the scene.
+int ensure_work(FrameWork& w, size_t n, hipStream_t stream) {
+    if (w.capacity >= n) return RT_OK;
+    if (n >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "too many rays in one launch");
+    w.release();
+    size_t tb = 0;
+    // The temporary size is asked for the widest key, so one workspace serves every key width.
+    HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n, 32, stream));
+    HIP_TRY(hipMalloc((void**)&w.samp, n * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&w.state, n * 4));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc((void**)&w.keys[k], n * 4));
+        HIP_TRY(hipMalloc((void**)&w.vals[k], n * 4));
+    }
+    HIP_TRY(hipMalloc(&w.temp, std::max<size_t>(tb, 16)));
+    w.temp_bytes = tb;
+    w.capacity = n;
+    return RT_OK;
+}
+
+// Projection from the sun across its dominant axis, scaled to the scene's bounds, and the number of
+// key bits to sort n shadow-ray candidates on.
+LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t n) {
+    LightProj lp{};
+    // Only the leading bits of the interleaved key are kept and sorted: the sort is stable, so the
+    // rays of one cell keep their screen order, which is coherent enough within a cell of a few
+    // hundred rays, and each 8 bits less saves one pass over the pairs. Key bits = log2(n / 512)
+    // rounded up to an even number, at least 16: a cell must stay narrower than the widest beam the
+    // walk accepts (1/128 of the scene) or the waves stop forming beams.
+    {
+        static const long env_bits = [] {
+            const char* e = std::getenv("RAYS_HIP_SORT_BITS");
+            return e ? std::atol(e) : 0L;
+        }();
+        uint32_t kb = 16;
+        while (kb < 32 && ((size_t)512 << kb) < n) kb += 2;
+        if (env_bits >= 2 && env_bits <= 32) kb = (uint32_t)env_bits & ~1u;
+        lp.key_bits = kb;
+    }
+    float c[3], dsun[3];
+    for (int k = 0; k < 3; ++k) {
+        c[k] = 0.5f * (s->bounds_lo[k] + s->bounds_hi[k]);
+        dsun[k] = std::fabs(c[k] - p->sun[k]);
+    }
+    lp.w = (dsun[0] >= dsun[1] && dsun[0] >= dsun[2]) ? 0 : (dsun[1] >= dsun[2] ? 1 : 2);
+    lp.a1 = lp.w == 0 ? 1 : 0;
+    lp.a2 = lp.w == 2 ? 1 : 2;
+    lp.sun_w = p->sun[lp.w];
+    lp.sun_a1 = p->sun[lp.a1];
+    lp.sun_a2 = p->sun[lp.a2];
+    float u0 = INFINITY, u1 = -INFINITY, v0 = INFINITY, v1 = -INFINITY;
+    bool ok = true;
+    for (int corner = 0; corner < 8; ++corner) {
+        float q[3];
+        for (int k = 0; k < 3; ++k) q[k] = (corner >> k) & 1 ? s->bounds_hi[k] : s->bounds_lo[k];
+        const float pw = q[lp.w] - lp.sun_w;
+        if (!(std::fabs(pw) > 0.0f)) ok = false;
+        const float u = (q[lp.a1] - lp.sun_a1) / pw, v = (q[lp.a2] - lp.sun_a2) / pw;
+        u0 = std::min(u0, u); u1 = std::max(u1, u);
+        v0 = std::min(v0, v); v1 = std::max(v1, v);
+    }
+    // The sun inside the scene's extent along w would make the projection change sign.
+    ok = ok && ((s->bounds_lo[lp.w] - lp.sun_w) * (s->bounds_hi[lp.w] - lp.sun_w) > 0.0f);
+    ok = ok && std::isfinite(u0) && std::isfinite(u1) && std::isfinite(v0) && std::isfinite(v1);
+    lp.u0 = ok ? u0 : 0.0f;
+    lp.v0 = ok ? v0 : 0.0f;
+    lp.uscale = (ok && u1 > u0) ? 65535.0f / (u1 - u0) : 0.0f;  // 0: every ray gets the same key
+    lp.vscale = (ok && v1 > v0) ? 65535.0f / (v1 - v0) : 0.0f;
+    return lp;
+}
+
 // events: null, or RT_RENDER_EVENTS hipEvent_t handles recorded around the phases.
 // primary_stats: null, or receives the counters as they stand after the camera-ray kernel.
 int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
@@ -217,7 +290,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     bool reflective = false;
     for (const DevObject& ob : s->objects) reflective = reflective || ob.reflectivity > 0.0f;
     const int mode = p->diffuse_depth > 1 ? 2 : ((reflective && p->reflect_depth > 1) ? 1 : 0);
-    if (mode != 0 || std::getenv("RAYS_HIP_MEGAKERNEL")) {
+    // One-kernel frame: mirror bounces, diffuse bounces over scenes with mirrors, or on request.
+    const bool pipeline = (mode == 0 || (mode == 2 && !reflective)) && !std::getenv("RAYS_HIP_MEGAKERNEL");
+    if (!pipeline) {
         HIP_TRY(mark(0));
         HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
         for (int k = 1; k < RT_RENDER_EVENTS; ++k) HIP_TRY(mark(k));
@@ -227,88 +302,70 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         }
         return RT_OK;
     }
-    // Camera + shadow rays only: primary kernel, light-space sort of the shadow rays, shadow
-    // kernel, resolve kernel.
-    const size_t n_slots = (size_t)dp.n_tiles * RT_TILE * RT_TILE * spp;
-    if (n_slots == 0) return RT_OK;
-    if (n_slots >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "frame has too many samples");
+    // Pipeline of small kernels. Camera + shadow rays only (mode 0): camera-ray kernel, light-space
+    // sort of the shadow rays, shadow kernel, resolve kernel, over the whole frame at once. With one
+    // diffuse bounce (mode 2): the same, then the scatter rays, their sorted shadow rays, and the
+    // resolve of both levels, over runs of tiles sized so that a run's scatter rays fit the
+    // workspace.
+    const uint32_t tile_slots = RT_TILE * RT_TILE * spp;
+    if ((size_t)dp.n_tiles * tile_slots >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "frame has too many samples");
+    if (dp.n_tiles == 0) return RT_OK;
+    uint32_t run_tiles = dp.n_tiles;
+    if (mode == 2) {
+        // Scatter rays per run of tiles (64 Mi: 2.3 GB of workspace); RAYS_HIP_BOUNCE_RAYS overrides.
+        const char* e = std::getenv("RAYS_HIP_BOUNCE_RAYS");
+        const long long v = e ? std::atoll(e) : 0;
+        const size_t cap = v > 0 ? (size_t)v : ((size_t)64 << 20);
+        const size_t per_tile = (size_t)tile_slots * p->diffuse_scatt;
+        if (per_tile >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many scatter rays per tile");
+        run_tiles = (uint32_t)std::min<size_t>(dp.n_tiles, std::max<size_t>(1, cap / per_tile));
+    }
+    const size_t run_slots = (size_t)run_tiles * tile_slots;
+    rc = ensure_work(s->work, run_slots, stream);
+    if (rc != RT_OK) return rc;
+    if (mode == 2) {
+        rc = ensure_work(s->bounce_work, run_slots * p->diffuse_scatt, stream);
+        if (rc != RT_OK) return rc;
+    }
     FrameWork& w = s->work;
-    if (w.capacity < n_slots) {
-        w.release();
-        size_t tb = 0;
-        // The temporary size is asked for the widest key, so one workspace serves every frame size.
-        HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n_slots, 32, stream));
-        HIP_TRY(hipMalloc((void**)&w.samp, n_slots * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&w.state, n_slots * 4));
-        for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipMalloc((void**)&w.keys[k], n_slots * 4));
-            HIP_TRY(hipMalloc((void**)&w.vals[k], n_slots * 4));
-        }
-        HIP_TRY(hipMalloc(&w.temp, std::max<size_t>(tb, 16)));
-        w.temp_bytes = tb;
-        w.capacity = n_slots;
-    }
-    // Projection from the sun across its dominant axis, scaled to the scene's bounds.
-    LightProj lp{};
-    // Only the leading bits of the interleaved key are kept and sorted: the sort is stable, so the
-    // rays of one cell keep their screen order, which is coherent enough within a cell of a few
-    // hundred rays, and each 8 bits less saves one pass over the pairs. Key bits = log2(n / 512)
-    // rounded up to an even number, at least 16: a cell must stay narrower than the widest beam the
-    // walk accepts (1/128 of the scene) or the waves stop forming beams.
-    {
-        static const long env_bits = [] {
-            const char* e = std::getenv("RAYS_HIP_SORT_BITS");
-            return e ? std::atol(e) : 0L;
-        }();
-        uint32_t kb = 16;
-        while (kb < 32 && ((size_t)512 << kb) < n_slots) kb += 2;
-        if (env_bits >= 2 && env_bits <= 32) kb = (uint32_t)env_bits & ~1u;
-        lp.key_bits = kb;
-    }
-    {
-        float c[3], dsun[3];
-        for (int k = 0; k < 3; ++k) {
-            c[k] = 0.5f * (s->bounds_lo[k] + s->bounds_hi[k]);
-            dsun[k] = std::fabs(c[k] - p->sun[k]);
-        }
-        lp.w = (dsun[0] >= dsun[1] && dsun[0] >= dsun[2]) ? 0 : (dsun[1] >= dsun[2] ? 1 : 2);
-        lp.a1 = lp.w == 0 ? 1 : 0;
-        lp.a2 = lp.w == 2 ? 1 : 2;
-        lp.sun_w = p->sun[lp.w];
-        lp.sun_a1 = p->sun[lp.a1];
-        lp.sun_a2 = p->sun[lp.a2];
-        float u0 = INFINITY, u1 = -INFINITY, v0 = INFINITY, v1 = -INFINITY;
-        bool ok = true;
-        for (int corner = 0; corner < 8; ++corner) {
-            float q[3];
-            for (int k = 0; k < 3; ++k) q[k] = (corner >> k) & 1 ? s->bounds_hi[k] : s->bounds_lo[k];
-            const float pw = q[lp.w] - lp.sun_w;
-            if (!(std::fabs(pw) > 0.0f)) ok = false;
-            const float u = (q[lp.a1] - lp.sun_a1) / pw, v = (q[lp.a2] - lp.sun_a2) / pw;
-            u0 = std::min(u0, u); u1 = std::max(u1, u);
-            v0 = std::min(v0, v); v1 = std::max(v1, v);
-        }
-        // The sun inside the scene's extent along w would make the projection change sign.
-        ok = ok && ((s->bounds_lo[lp.w] - lp.sun_w) * (s->bounds_hi[lp.w] - lp.sun_w) > 0.0f);
-        ok = ok && std::isfinite(u0) && std::isfinite(u1) && std::isfinite(v0) && std::isfinite(v1);
-        lp.u0 = ok ? u0 : 0.0f;
-        lp.v0 = ok ? v0 : 0.0f;
-        lp.uscale = (ok && u1 > u0) ? 65535.0f / (u1 - u0) : 0.0f;  // 0: every ray gets the same key
-        lp.vscale = (ok && v1 > v0) ? 65535.0f / (v1 - v0) : 0.0f;
-    }
+    FrameWork& bw = s->bounce_work;
+    const uint32_t total_tiles = dp.n_tiles;
     HIP_TRY(mark(0));
-    HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], w.vals[0], d_stats, stream));
-    HIP_TRY(mark(1));
-    if (primary_stats && d_stats) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
+    for (uint32_t first = 0; first < total_tiles; first += run_tiles) {
+        const bool last_run = first + run_tiles >= total_tiles;
+        dp.tile_first = first;
+        dp.n_tiles = std::min(run_tiles, total_tiles - first);
+        const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
+        const LightProj lp = light_projection(s, p, n_slots);
+        HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], w.vals[0], d_stats, stream));
+        if (last_run) HIP_TRY(mark(1));
+        if (primary_stats && d_stats && last_run) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
+        }
+        size_t tb = w.temp_bytes;
+        HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], w.vals[0], w.vals[1], n_slots, lp.key_bits, stream));
+        if (last_run) HIP_TRY(mark(2));
+        HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
+                               w.vals[1], w.samp, w.state, d_stats, stream));
+        if (mode == 0) {
+            if (last_run) HIP_TRY(mark(3));
+            HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
+        } else {
+            const size_t n_rays = n_slots * p->diffuse_scatt;
+            const LightProj lp2 = light_projection(s, p, n_rays);
+            HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, d_list, (uint32_t)n_rays, w.samp, w.state, bw.samp, bw.state,
+                                   bw.keys[0], bw.vals[0], d_stats, stream));
+            size_t tb2 = bw.temp_bytes;
+            HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], bw.vals[0], bw.vals[1], n_rays,
+                                        lp2.key_bits, stream));
+            HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_rays, lp2.key_bits > 16 ? lp2.key_bits - 16 : 0u,
+                                   bw.keys[1], bw.vals[1], bw.samp, bw.state, d_stats, stream));
+            if (last_run) HIP_TRY(mark(3));
+            HIP_TRY(rtk::wf_resolve_diffuse(s->view, dp, d_list, w.samp, w.state, bw.samp, bw.state, d_rgba8, d_hit_ids,
+                                            stream));
+        }
     }
-    size_t tb = w.temp_bytes;
-    HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], w.vals[0], w.vals[1], n_slots, lp.key_bits, stream));
-    HIP_TRY(mark(2));
-    HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1], w.vals[1], w.samp, w.state, d_stats, stream));
-    HIP_TRY(mark(3));
-    HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
     HIP_TRY(mark(4));
     return RT_OK;
 }

@@ -9,8 +9,12 @@
 
 #define RT_BLOCK 256        // threads per workgroup: four 64-lane waves
 #define RT_BLOCK0 256       // workgroup of the frame megakernel when it needs no per-lane stacks
+#ifndef RT_STACK_LDS
 #define RT_STACK_LDS 16     // traversal stack entries kept in LDS per lane
+#endif
+#ifndef RT_STACK_SPILL
 #define RT_STACK_SPILL 80   // further entries in private memory
+#endif
 #define RT_STACK_MAX (RT_STACK_LDS + RT_STACK_SPILL)
 #define RT_MAX_REFLECT 8    // deepest mirror chain the frame kernel keeps on its stack
 #define RT_BEAM_LEVELS 16   // wide-tree levels whose pending children a wave keeps in LDS
@@ -55,6 +59,7 @@ struct DevRenderParams {
     uint32_t seed;
     uint32_t tiles_x;          // tiles per row of the frame
     uint32_t n_tiles;          // tiles this launch renders
+    uint32_t tile_first;       // position of the launch's first tile in the frame's (or shard's) tile order
     uint32_t compact;          // 1: write tile-compact output, 0: write the frame in place
     uint32_t beam_levels;      // deepest wide tree of the scene (levels of pending children kept in LDS)
 };

@@ -30,6 +30,14 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
                      DevStats* d_stats, hipStream_t s);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
+// One diffuse bounce as a pipeline (scenes without mirrors): scatter rays of the launch's samples,
+// then shading of both levels. n_rays = sample slots of the launch * p.diffuse_scatt.
+hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
+                     uint32_t n_rays, const float4* d_samp, const uint32_t* d_state, float4* d_dsamp, uint32_t* d_dstate,
+                     uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats, hipStream_t s);
+hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list,
+                              const float4* d_samp, const uint32_t* d_state, const float4* d_dsamp,
+                              const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
 // Stable radix sort of (u32 key, u32 value) pairs on the low key_bits bits of the key. With
 // temp == nullptr only *temp_bytes is set.
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,

@@ -871,7 +871,10 @@ __device__ __forceinline__ void flush_stats(const LaneStats& st, DevStats* out) 
 // ---------------------------------------------------------------------------------------------
 // Batch kernels
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(SceneView sv, const rt_ray* __restrict__ rays,
+#ifndef RT_LANE_WAVES
+#define RT_LANE_WAVES 8
+#endif
+__global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(SceneView sv, const rt_ray* __restrict__ rays,
                                                           uint64_t n, rt_hit* __restrict__ out) {
     __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -889,7 +892,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(SceneView sv, const 
     out[i] = o;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_any(SceneView sv, const rt_ray* __restrict__ rays,
+// The same search with the wave-coherent walks (beam where the wave's rays form one, mask walk
+// otherwise): for batches whose consecutive rays are neighbours.
+__global__ __launch_bounds__(64, 8) void k_trace_closest_wave(SceneView sv, const rt_ray* __restrict__ rays, uint64_t n,
+                                                             uint32_t beam_levels, rt_hit* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint2* s_beam = reinterpret_cast<uint2*>(s_dyn);
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool act = i < n;
+    LaneStats st;
+    rt_ray r;
+    if (act) r = rays[i];
+    else r = rt_ray{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}};
+    const HitD h = closest_all_packet<false>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), act, s_beam, st);
+    if (act) {
+        rt_hit o;
+        o.tri = h.tri;
+        o.t = h.t;
+        o.u = h.u;
+        o.v = h.v;
+        out[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_any(SceneView sv, const rt_ray* __restrict__ rays,
                                                       uint64_t n, uint8_t* __restrict__ occluded) {
     __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1154,6 +1180,20 @@ __device__ __forceinline__ void sample_offset(uint32_t grid, uint32_t s, float* 
 // diffuse bounces, which scatter, are traced per lane.
 // MODE 0: camera + shadow rays only (no reflective object or reflect_depth <= 1, diffuse_depth <= 1)
 // MODE 1: + mirror chains     MODE 2: + diffuse scattering at depth 1
+// Scatter direction k of a sample: cosine-weighted about the normal, src/main.rs:259-279, with the
+// counter generator in place of rand::random.
+__device__ __forceinline__ rt_f3 diffuse_dir(uint32_t seed, uint64_t sample_index, uint32_t k, rt_f3 normal, rt_f3 tang1,
+                                             rt_f3 tang2) {
+    const float sin_theta = __builtin_sqrtf(counter_rand(seed, sample_index, k, 0));
+    const float cos_theta = __builtin_sqrtf(1.0f - sin_theta * sin_theta);
+    const float psi = counter_rand(seed, sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
+    const float a = sin_theta * cosf(psi);
+    const float b = sin_theta * sinf(psi);
+    const float c = cos_theta;
+    return g_normalize(f3(a * tang1.x + b * tang2.x + c * normal.x, a * tang1.y + b * tang2.y + c * normal.y,
+                          a * tang1.z + b * tang2.z + c * normal.z));
+}
+
 template <int MODE, bool STATS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams p,
                                                   const uint32_t* __restrict__ tile_list,
@@ -1222,15 +1262,7 @@ __global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams 
             rt_f3 tang1, tang2;
             tangent_vectors(sf.normal, &tang1, &tang2);
             for (uint32_t k = 0; k < p.diffuse_scatt; ++k) {
-                const float sin_theta = __builtin_sqrtf(counter_rand(p.seed, sample_index, k, 0));
-                const float cos_theta = __builtin_sqrtf(1.0f - sin_theta * sin_theta);
-                const float psi = counter_rand(p.seed, sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
-                const float a = sin_theta * cosf(psi);
-                const float b = sin_theta * sinf(psi);
-                const float c = cos_theta;
-                const rt_f3 vel = g_normalize(f3(a * tang1.x + b * tang2.x + c * sf.normal.x,
-                                                 a * tang1.y + b * tang2.y + c * sf.normal.y,
-                                                 a * tang1.z + b * tang2.z + c * sf.normal.z));
+                const rt_f3 vel = diffuse_dir(p.seed, sample_index, k, sf.normal, tang1, tang2);
                 const float light_power = g_dot(sf.normal, vel);
                 const Col col = mirror_chain<STATS>(sv, p, sf.pos, vel, 2, stk, st);
                 diffuse_color = cadd(diffuse_color, cmul(cmul_col(col, sf.color), light_power * sf.roughness));
@@ -1307,16 +1339,17 @@ static inline uint32_t xcd_grid(uint32_t blocks) {
 
 template <int BLOCK>
 struct PixelMap {
-    uint32_t x, y, s, mx, my, local_tile, block;
+    uint32_t x, y, s, mx, my, local_tile, launch_tile, block;
     bool inside;
     __device__ __forceinline__ PixelMap(const DevRenderParams& p, const uint32_t* tile_list, bool remap = false) {
         const uint32_t spp = p.spp;
         const uint32_t ppb = BLOCK / spp;
         const uint32_t blocks_per_tile = (RT_TILE * RT_TILE) / ppb;
         block = remap ? xcd_block(blockIdx.x) : blockIdx.x;
-        local_tile = block / blocks_per_tile;
+        launch_tile = block / blocks_per_tile;
+        local_tile = p.tile_first + launch_tile;
         const uint32_t block_in_tile = block % blocks_per_tile;
-        const uint32_t tile = (tile_list && local_tile < p.n_tiles) ? tile_list[local_tile] : local_tile;
+        const uint32_t tile = (tile_list && launch_tile < p.n_tiles) ? tile_list[local_tile] : local_tile;
         const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
         s = threadIdx.x % spp;
         const uint32_t pix_in_tile = block_in_tile * ppb + threadIdx.x / spp;
@@ -1352,6 +1385,20 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v) {
     return v;
 }
 
+// Light-space sort key of a shadow ray's origin: the point projected from the sun onto the plane
+// across the light's dominant axis; points on one line to the sun get (nearly) one key.
+__device__ __forceinline__ uint32_t light_key(const LightProj& lp, rt_f3 pos) {
+    const float pw = pick3(pos, lp.w) - lp.sun_w;
+    const float rw = 1.0f / pw;
+    const float u = (pick3(pos, lp.a1) - lp.sun_a1) * rw;
+    const float v = (pick3(pos, lp.a2) - lp.sun_a2) * rw;
+    const float qu = fminf(fmaxf((u - lp.u0) * lp.uscale, 0.0f), 65535.0f);
+    const float qv = fminf(fmaxf((v - lp.v0) * lp.vscale, 0.0f), 65535.0f);
+    uint32_t key = spread16((uint32_t)qu) | (spread16((uint32_t)qv) << 1);
+    if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
+    return key >> (32u - lp.key_bits);  // below 32 bits no key can equal the all-ones "no shadow ray" value
+}
+
 // Minimum waves per SIMD the camera- and shadow-ray kernels are compiled for: 8 keeps them at
 // <= 64 VGPRs, which measured 10 % faster than the 81 VGPRs the compiler picks unconstrained.
 #ifndef RT_WF_WAVES
@@ -1371,7 +1418,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
     const PixelMap<BLOCK> pm(p, tile_list, true);
-    if (pm.local_tile >= p.n_tiles) return;  // padding of the renumbered launch
+    if (pm.launch_tile >= p.n_tiles) return;  // padding of the renumbered launch
     LaneStats st;
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
@@ -1387,19 +1434,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
     // Light-space key: the hit point projected from the sun onto the plane across the light's
     // dominant axis; points on one line to the sun get (nearly) one key.
-    uint32_t key = 0xFFFFFFFFu;
-    if (lit) {
-        const float pw = pick3(sf.pos, lp.w) - lp.sun_w;
-        const float rw = 1.0f / pw;
-        const float u = (pick3(sf.pos, lp.a1) - lp.sun_a1) * rw;
-        const float v = (pick3(sf.pos, lp.a2) - lp.sun_a2) * rw;
-        const float qu = fminf(fmaxf((u - lp.u0) * lp.uscale, 0.0f), 65535.0f);
-        const float qv = fminf(fmaxf((v - lp.v0) * lp.vscale, 0.0f), 65535.0f);
-        key = spread16((uint32_t)qu) | (spread16((uint32_t)qv) << 1);
-        if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
-        key >>= 32u - lp.key_bits;  // below 32 bits no key can equal the all-ones "no shadow ray" value
-    }
-    keys[slot] = key;
+    keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
     vals[slot] = slot;
     if (STATS) flush_stats(st, stats);
 }
@@ -1479,6 +1514,169 @@ __global__ __launch_bounds__(BLOCK) void k_wf_resolve(SceneView sv, DevRenderPar
 // Scatter of gathered tile-compact slabs into a frame. Tile t belongs to shard (tx + ty) % count;
 // its slot inside the shard's slab is its rank among that shard's tiles in ascending tile id,
 // given by tile_slot[t].
+// ---------------------------------------------------------------------------------------------
+// Frames with one diffuse bounce (DIFFUSE_DEPTH = 2) over scenes without mirrors, as a pipeline:
+//   k_wf_primary, sort, k_wf_shadow       camera rays and their shadow rays, as above
+//   k_wf_bounce                           the scatter rays of every hit sample: nearest hit by the
+//                                         per-lane walk (they share an origin, not a direction); per
+//                                         ray: hit point, id, state, light-space key
+//   sort, k_wf_shadow                     the scatter rays' shadow rays, in light-space order
+//   k_wf_resolve_diffuse                  shading of both levels, gamma, average, RGBA8
+// Scatter ray j of a launch belongs to sample slot j / scatt, direction j % scatt. Small kernels
+// instead of one: the per-lane walk needs occupancy more than anything (8 waves per SIMD here, 3 in
+// the one-kernel frame), and half of the bounce level's rays are shadow rays that the sorted beam
+// walk handles an order of magnitude faster.
+// ---------------------------------------------------------------------------------------------
+// Pixel and sample of a launch-relative sample slot (the inverse of PixelMap's slot numbering).
+struct SlotMap {
+    uint32_t x, y, s;
+    uint64_t sample_index;
+    bool inside;
+    __device__ __forceinline__ SlotMap(const DevRenderParams& p, const uint32_t* tile_list, uint32_t slot) {
+        const uint32_t per_tile = RT_TILE * RT_TILE * p.spp;
+        const uint32_t launch_tile = slot / per_tile, rest = slot % per_tile;
+        const uint32_t local_tile = p.tile_first + launch_tile;
+        const uint32_t tile = tile_list ? tile_list[local_tile] : local_tile;
+        const uint32_t pix_in_tile = rest / p.spp;
+        s = rest % p.spp;
+        uint32_t mx = 0, my = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            mx |= ((pix_in_tile >> (2 * b)) & 1u) << b;
+            my |= ((pix_in_tile >> (2 * b + 1)) & 1u) << b;
+        }
+        x = (tile % p.tiles_x) * RT_TILE + mx;
+        y = (tile / p.tiles_x) * RT_TILE + my;
+        inside = x < p.width && y < p.height;
+        sample_index = ((uint64_t)y * p.width + x) * p.spp + s;
+    }
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp,
+                                                                       const uint32_t* __restrict__ tile_list,
+                                                                       uint32_t n_rays,
+                                                                       const float4* __restrict__ samp,
+                                                                       const uint32_t* __restrict__ state,
+                                                                       float4* __restrict__ dsamp,
+                                                                       uint32_t* __restrict__ dstate,
+                                                                       uint32_t* __restrict__ dkeys,
+                                                                       uint32_t* __restrict__ dvals,
+                                                                       DevStats* __restrict__ stats) {
+    __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool act = j < n_rays;
+    LaneStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    LaneStats st;
+    const uint32_t slot = j / p.diffuse_scatt, k = j % p.diffuse_scatt;
+    const uint32_t stt = act ? state[slot] : 0u;
+    uint32_t out_state = 0, key = 0xFFFFFFFFu;
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS));
+    if (stt & RT_ST_HIT) {
+        const SlotMap sm(p, tile_list, slot);
+        const float4 a = samp[slot];
+        const rt_f3 pos = f3(a.x, a.y, a.z);
+        const rt_f3 normal = ld3(sv.tri_data + 6 * (size_t)__float_as_uint(a.w));
+        rt_f3 tang1, tang2;
+        tangent_vectors(normal, &tang1, &tang2);
+        const rt_f3 vel = diffuse_dir(p.seed, sm.sample_index, k, normal, tang1, tang2);
+        const HitD h = closest_all<STATS>(sv, pos, vel, stk, st);
+        if (h.tri != RT_MISS) {
+            const Surface s2 = surface_of(sv, h, pos, vel);
+            const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+            const rt_f3 sun_dir = g_normalize(sun - s2.pos);
+            const bool lit = g_dot(s2.normal, sun_dir) > 0.0f;
+            out = make_float4(s2.pos.x, s2.pos.y, s2.pos.z, __uint_as_float(h.tri));
+            out_state = RT_ST_HIT | (lit ? RT_ST_LIT : 0u) | (h.obj << 8);
+            if (lit) key = light_key(lp, s2.pos);
+        }
+    }
+    if (act) {
+        dsamp[j] = out;
+        dstate[j] = out_state;
+        dkeys[j] = key;
+        dvals[j] = j;
+    }
+    if (STATS) flush_stats(st, stats);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_wf_resolve_diffuse(SceneView sv, DevRenderParams p,
+                                                              const uint32_t* __restrict__ tile_list,
+                                                              const float4* __restrict__ samp,
+                                                              const uint32_t* __restrict__ state,
+                                                              const float4* __restrict__ dsamp,
+                                                              const uint32_t* __restrict__ dstate,
+                                                              uint8_t* __restrict__ rgba8,
+                                                              uint32_t* __restrict__ hit_ids) {
+    __shared__ float s_col[3 * BLOCK];
+    const PixelMap<BLOCK> pm(p, tile_list);
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const float4 a = samp[slot];
+    const uint32_t stt = state[slot];
+    const uint32_t tri = __float_as_uint(a.w);
+    const bool hit_any = (stt & RT_ST_HIT) != 0u;
+    const uint32_t spp = p.spp;
+    Col color{0.0f, 0.0f, 0.0f};
+    if (hit_any) {
+        // The operations of k_render<2> on the stored hit points, in its order.
+        const float* td = sv.tri_data + 6 * (size_t)tri;
+        const rt_f3 normal = ld3(td);
+        const Col tcol = Col{td[3], td[4], td[5]};
+        const rt_f3 pos = f3(a.x, a.y, a.z);
+        const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+        const rt_f3 sun_dir = g_normalize(sun - pos);
+        const DevObject& ob = sv.objs[stt >> 8];
+        if ((stt & RT_ST_LIT) && !(stt & RT_ST_OCC)) color = cmul(tcol, g_dot(normal, sun_dir) * ob.albedo);
+        const uint64_t sample_index = ((uint64_t)pm.y * p.width + pm.x) * spp + pm.s;
+        rt_f3 tang1, tang2;
+        tangent_vectors(normal, &tang1, &tang2);
+        Col diffuse_color{0.0f, 0.0f, 0.0f};
+        for (uint32_t k = 0; k < p.diffuse_scatt; ++k) {
+            const rt_f3 vel = diffuse_dir(p.seed, sample_index, k, normal, tang1, tang2);
+            const float light_power = g_dot(normal, vel);
+            const size_t j = (size_t)slot * p.diffuse_scatt + k;
+            const uint32_t st2 = dstate[j];
+            Col col = sky();
+            if (st2 & RT_ST_HIT) {
+                col = Col{0.0f, 0.0f, 0.0f};
+                if ((st2 & RT_ST_LIT) && !(st2 & RT_ST_OCC)) {
+                    const float4 b = dsamp[j];
+                    const float* td2 = sv.tri_data + 6 * (size_t)__float_as_uint(b.w);
+                    const rt_f3 sun_dir2 = g_normalize(sun - f3(b.x, b.y, b.z));
+                    col = cmul(Col{td2[3], td2[4], td2[5]}, g_dot(ld3(td2), sun_dir2) * sv.objs[st2 >> 8].albedo);
+                }
+            }
+            diffuse_color = cadd(diffuse_color, cmul(cmul_col(col, tcol), light_power * ob.roughness));
+        }
+        diffuse_color = cdiv(diffuse_color, (float)p.diffuse_scatt);
+        color = cadd(color, Col{0.0f, 0.0f, 0.0f});  // the mirror term of a surface that reflects nothing
+        color = cadd(color, diffuse_color);
+        color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+    } else {
+        color = pm.inside ? sky() : Col{0.0f, 0.0f, 0.0f};
+    }
+    if (hit_ids && pm.inside) hit_ids[((uint64_t)pm.y * p.width + pm.x) * spp + pm.s] = tri;
+    s_col[3 * threadIdx.x + 0] = color.r;
+    s_col[3 * threadIdx.x + 1] = color.g;
+    s_col[3 * threadIdx.x + 2] = color.b;
+    __syncthreads();
+    if (pm.s == 0 && pm.inside) {
+        Col acc = color;
+        for (uint32_t k = 1; k < spp; ++k) {
+            const float* c = &s_col[3 * (threadIdx.x + k)];
+            acc = cadd(acc, Col{c[0], c[1], c[2]});
+        }
+        acc = cdiv(acc, (float)spp);
+        const uint32_t px = to_u8(acc.r) | (to_u8(acc.g) << 8) | (to_u8(acc.b) << 16) | 0xff000000u;
+        size_t off;
+        if (p.compact) off = ((size_t)pm.local_tile * RT_TILE * RT_TILE + (size_t)pm.my * RT_TILE + pm.mx) * 4;
+        else off = ((size_t)pm.y * p.width + pm.x) * 4;
+        *reinterpret_cast<uint32_t*>(rgba8 + off) = px;
+    }
+}
+
 __global__ void k_deinterleave(const uint8_t* __restrict__ gathered, const uint32_t* __restrict__ tile_slot,
                                uint32_t slab_tiles, uint32_t width, uint32_t height, uint32_t tiles_x,
                                uint32_t shard_count, uint8_t* __restrict__ rgba8) {
@@ -1507,7 +1705,12 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 
 hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_out);
+    static const bool wave_walk = std::getenv("RAYS_HIP_TRACE_WAVE") != nullptr;
+    if (wave_walk)
+        hipLaunchKernelGGL(k_trace_closest_wave, dim3(grid_for(n, 64)), dim3(64), (size_t)RT_BEAM_LEVELS * 64 * 8, s, sv,
+                           d_rays, n, (uint32_t)RT_BEAM_LEVELS, d_out);
+    else
+        hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_out);
     return hipGetLastError();
 }
 
@@ -1604,6 +1807,29 @@ hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint3
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL((k_wf_resolve<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_samp, d_state,
                        d_rgba8, d_hit_ids);
+    return hipGetLastError();
+}
+
+hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
+                     uint32_t n_rays, const float4* d_samp, const uint32_t* d_state, float4* d_dsamp, uint32_t* d_dstate,
+                     uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats, hipStream_t s) {
+    if (n_rays == 0) return hipSuccess;
+    if (d_stats)
+        hipLaunchKernelGGL((k_wf_bounce<true>), dim3(grid_for(n_rays, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, p, lp,
+                           d_tile_list, n_rays, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
+    else
+        hipLaunchKernelGGL((k_wf_bounce<false>), dim3(grid_for(n_rays, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, p, lp,
+                           d_tile_list, n_rays, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
+    return hipGetLastError();
+}
+
+hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list,
+                              const float4* d_samp, const uint32_t* d_state, const float4* d_dsamp,
+                              const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s) {
+    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_wf_resolve_diffuse<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_samp,
+                       d_state, d_dsamp, d_dstate, d_rgba8, d_hit_ids);
     return hipGetLastError();
 }
 

@@ -206,6 +206,39 @@ def test_render_soup_primary_and_shadow(soup_pair):
     _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
 
 
+def test_render_soup_diffuse_bounce_pipeline(soup_pair, monkeypatch):
+    """One diffuse bounce over a scene without mirrors runs as a pipeline of kernels (scatter rays,
+    sorted shadow rays, resolve). It must agree with the oracle, and byte for byte with the
+    one-kernel frame, also when the frame is cut into several runs of tiles."""
+    g, o = soup_pair
+    W, H = 96, 80
+    kw = dict(reflect_depth=4, diffuse_depth=2)
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
+    p = render_params(W, H, 2, **kw)
+    rgba, ids = g.render(p, want_hit_ids=True)
+    same = ids == ref_ids
+    assert 1.0 - same.mean() <= 1e-5
+    ok = same.reshape(-1, 4).all(axis=1).reshape(ref_rgba.shape[:2])
+    d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16))[ok]
+    # Scatter rays start from computed hit points and use sin/cos: a 1-ulp libm difference can flip
+    # a far bounce; allow a thin tail beyond 1 LSB and bound it.
+    assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
+    monkeypatch.setenv("RAYS_HIP_BOUNCE_RAYS", str(3 * 1024 * 4 * 10))   # three tiles per run
+    rgba_runs, ids_runs = g.render(p, want_hit_ids=True)
+    assert np.array_equal(rgba_runs, rgba) and np.array_equal(ids_runs, ids)
+    monkeypatch.delenv("RAYS_HIP_BOUNCE_RAYS")
+    monkeypatch.setenv("RAYS_HIP_MEGAKERNEL", "1")
+    rgba_one, ids_one = g.render(p, want_hit_ids=True)
+    assert np.array_equal(ids_one, ids)
+    assert np.array_equal(rgba_one, rgba), f"{(rgba_one != rgba).sum()} bytes differ from the one-kernel frame"
+    # sharded, compact output
+    monkeypatch.delenv("RAYS_HIP_MEGAKERNEL")
+    acc = np.zeros_like(rgba)
+    for r in range(2):
+        acc |= g.render(render_params(W, H, 2, shard_index=r, shard_count=2, **kw))
+    assert np.array_equal(acc, rgba)
+
+
 def test_render_sharded_tiles_cover_the_frame(teapot_pair):
     g, _ = teapot_pair
     W, H = 200, 120  # not a multiple of the tile size
