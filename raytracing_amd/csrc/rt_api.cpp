@@ -86,13 +86,28 @@ struct rt_ctx {
     int device = 0;
     std::mutex mu;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, TileMap> tile_maps;
+    // Work counters of the persistent kernels: one per launch, taken in turn, so that launches in
+    // flight on different streams do not share one.
+    static constexpr uint32_t N_COUNTERS = 256;
+    uint32_t* d_counters = nullptr;
+    uint32_t next_counter = 0;
     ~rt_ctx() {
+        if (d_counters) (void)hipFree(d_counters);
         for (auto& kv : tile_maps) {
             if (kv.second.d_list) (void)hipFree(kv.second.d_list);
             if (kv.second.d_slot) (void)hipFree(kv.second.d_slot);
         }
     }
 };
+
+// A zeroed work counter for one launch on `stream` (the caller holds ctx->mu).
+int take_counter(rt_ctx* ctx, hipStream_t stream, uint32_t** out) {
+    if (!ctx->d_counters) HIP_TRY(hipMalloc((void**)&ctx->d_counters, rt_ctx::N_COUNTERS * 64));
+    uint32_t* c = ctx->d_counters + 16 * (ctx->next_counter++ % rt_ctx::N_COUNTERS);
+    HIP_TRY(hipMemsetAsync(c, 0, 4, stream));
+    *out = c;
+    return RT_OK;
+}
 
 // Per-sample buffers of the camera + shadow pipeline, grown on demand and kept with the scene.
 struct FrameWork {
@@ -354,8 +369,11 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         } else {
             const size_t n_rays = n_slots * p->diffuse_scatt;
             const LightProj lp2 = light_projection(s, p, n_rays);
-            HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, d_list, (uint32_t)n_rays, w.samp, w.state, bw.samp, bw.state,
-                                   bw.keys[0], bw.vals[0], d_stats, stream));
+            uint32_t* counter = nullptr;
+            rc = take_counter(s->ctx, stream, &counter);
+            if (rc != RT_OK) return rc;
+            HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, d_list, (uint32_t)n_rays, counter, w.samp, w.state, bw.samp,
+                                   bw.state, bw.keys[0], bw.vals[0], d_stats, stream));
             size_t tb2 = bw.temp_bytes;
             HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], bw.vals[0], bw.vals[1], n_rays,
                                         lp2.key_bits, stream));
@@ -663,7 +681,12 @@ int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hi
     if (n == 0) return RT_OK;
     if (!d_rays || !d_out) return fail(RT_ERR_INVALID, "null buffer");
     if (n > (1ull << 31) * RT_BLOCK) return fail(RT_ERR_INVALID, "too many rays in one call");
-    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    uint32_t* counter = nullptr;
+    int rc = take_counter(s->ctx, (hipStream_t)stream, &counter);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, counter, (hipStream_t)stream));
     return RT_OK;
 }
 
@@ -703,7 +726,9 @@ extern "C" {
 
 int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* out) {
     return trace_host<rt_hit>(s, rays, n, out, [&](const rt_ray* dr, rt_hit* dout) {
-        return rtk::trace_closest(s->view, dr, n, dout, 0);
+        uint32_t* counter = nullptr;
+        if (take_counter(s->ctx, 0, &counter) != RT_OK) return hipErrorOutOfMemory;
+        return rtk::trace_closest(s->view, dr, n, dout, counter, 0);
     });
 }
 

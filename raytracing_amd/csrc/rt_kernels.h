@@ -10,7 +10,9 @@
 
 namespace rtk {
 
-hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, hipStream_t s);
+// d_counter: a zeroed device word for the persistent kernel's ray hand-out.
+hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, uint32_t* d_counter,
+                         hipStream_t s);
 hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, hipStream_t s);
 hipError_t trace_closest_linear(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
                                 hipStream_t s);
@@ -33,8 +35,9 @@ hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint3
 // One diffuse bounce as a pipeline (scenes without mirrors): scatter rays of the launch's samples,
 // then shading of both levels. n_rays = sample slots of the launch * p.diffuse_scatt.
 hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                     uint32_t n_rays, const float4* d_samp, const uint32_t* d_state, float4* d_dsamp, uint32_t* d_dstate,
-                     uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats, hipStream_t s);
+                     uint32_t n_rays, uint32_t* d_counter, const float4* d_samp, const uint32_t* d_state,
+                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats,
+                     hipStream_t s);
 hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list,
                               const float4* d_samp, const uint32_t* d_state, const float4* d_dsamp,
                               const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);

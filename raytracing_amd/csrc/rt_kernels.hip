@@ -8,6 +8,9 @@
 
 #include "rt_kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "rt_exact.h"
 
 using rtbvh::EMPTY;
@@ -35,23 +38,26 @@ __device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2
 // Per-lane traversal stack: RT_STACK_LDS entries in LDS (lane-interleaved, conflict-free
 // 8-byte accesses), the rest in private memory. An entry is (node reference, entry distance).
 // ---------------------------------------------------------------------------------------------
-struct LaneStack {
-    uint2* lds;    // &s_stack[threadIdx.x]; entry e lives at lds[e * RT_BLOCK]
-    uint2 spill[RT_STACK_SPILL];
+template <int NLDS, int STRIDE>
+struct LaneStackT {
+    static_assert(NLDS <= RT_STACK_MAX, "stack split");
+    uint2* lds;    // &s_stack[threadIdx.x]; entry e lives at lds[e * STRIDE] (STRIDE = workgroup size)
+    uint2 spill[RT_STACK_MAX - NLDS];
     int sp;
     __device__ __forceinline__ void push(uint32_t node, float tnear) {
         uint2 e = make_uint2(node, __float_as_uint(tnear));
-        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = e;
-        else if (sp < RT_STACK_MAX) spill[sp - RT_STACK_LDS] = e;
+        if (sp < NLDS) lds[sp * STRIDE] = e;
+        else if (sp < RT_STACK_MAX) spill[sp - NLDS] = e;
         // The host refuses trees whose pending-entry bound exceeds RT_STACK_MAX, so the
         // stack cannot overflow; the guard above only keeps a corrupt tree from writing wild.
         sp = sp < RT_STACK_MAX ? sp + 1 : sp;
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
-        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[sp - RT_STACK_LDS];
+        return sp < NLDS ? lds[sp * STRIDE] : spill[sp - NLDS];
     }
 };
+using LaneStack = LaneStackT<RT_STACK_LDS, RT_BLOCK>;
 
 #define RT_CSWAP(ka, kb, ca, cb)            \
     {                                       \
@@ -71,28 +77,23 @@ struct LaneStack {
 // Shadow mode (ANY == true) returns at the first triangle whose lane of the reference's result
 // has a clear sign bit (src/main.rs:199-204). A NaN t is treated as a miss: x86 produces
 // NaNs with the sign bit set, gfx950 with it clear.
-template <bool ANY, bool STATS>
-__device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, uint32_t obj_index, rt_f3 o,
-                                           rt_f3 d, rt_f3 inv, float& closest, HitD& hit, LaneStack& stk,
-                                           LaneStats& st) {
-    const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
-    uint32_t local_best = 0;
-    stk.sp = 0;
-    uint32_t cur = root;
-    for (;;) {
-        if (!(cur & LEAF_BIT)) {
-            const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
-            // child k = (lo.x lo.y lo.z hi.x) (hi.y hi.z ref pad)
-            const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3];
-            const float4 a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
-            if (STATS) {
-                st.node += 1;
-                st.box += 4;
-                st.bytes += 128;
-            }
-            float k0, k1, k2, k3;
-            uint32_t c0 = __float_as_uint(b0.z), c1 = __float_as_uint(b1.z);
-            uint32_t c2 = __float_as_uint(b2.z), c3 = __float_as_uint(b3.z);
+// One inner node for one ray: tests the four children, pushes the far ones (farthest first) and
+// returns the nearest in *next; false when the ray meets none of them.
+template <bool STATS, class Stack>
+__device__ __forceinline__ bool node_step(const SceneView& sv, uint32_t cur, rt_f3 inv, float nox, float noy, float noz,
+                                          float closest, Stack& stk, LaneStats& st, uint32_t* next) {
+    const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
+    // child k = (lo.x lo.y lo.z hi.x) (hi.y hi.z ref pad)
+    const float4 a0 = np[0], b0 = np[1], a1 = np[2], b1 = np[3];
+    const float4 a2 = np[4], b2 = np[5], a3 = np[6], b3 = np[7];
+    if (STATS) {
+        st.node += 1;
+        st.box += 4;
+        st.bytes += 128;
+    }
+    float k0, k1, k2, k3;
+    uint32_t c0 = __float_as_uint(b0.z), c1 = __float_as_uint(b1.z);
+    uint32_t c2 = __float_as_uint(b2.z), c3 = __float_as_uint(b3.z);
 #define RT_BOX(K, C, A, B)                                                                           \
     {                                                                                                \
         float ax = __builtin_fmaf(A.x, inv.x, nox), bx = __builtin_fmaf(A.w, inv.x, nox);            \
@@ -102,53 +103,76 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
         float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));        \
         K = ((C) != EMPTY && tn <= tf) ? tn : RT_INF;                                                \
     }
-            RT_BOX(k0, c0, a0, b0)
-            RT_BOX(k1, c1, a1, b1)
-            RT_BOX(k2, c2, a2, b2)
-            RT_BOX(k3, c3, a3, b3)
+    RT_BOX(k0, c0, a0, b0)
+    RT_BOX(k1, c1, a1, b1)
+    RT_BOX(k2, c2, a2, b2)
+    RT_BOX(k3, c3, a3, b3)
 #undef RT_BOX
-            RT_CSWAP(k0, k1, c0, c1)
-            RT_CSWAP(k2, k3, c2, c3)
-            RT_CSWAP(k0, k2, c0, c2)
-            RT_CSWAP(k1, k3, c1, c3)
-            RT_CSWAP(k1, k2, c1, c2)
-            if (k3 < RT_INF) stk.push(c3, k3);
-            if (k2 < RT_INF) stk.push(c2, k2);
-            if (k1 < RT_INF) stk.push(c1, k1);
-            if (k0 < RT_INF) {
-                cur = c0;
+    RT_CSWAP(k0, k1, c0, c1)
+    RT_CSWAP(k2, k3, c2, c3)
+    RT_CSWAP(k0, k2, c0, c2)
+    RT_CSWAP(k1, k3, c1, c3)
+    RT_CSWAP(k1, k2, c1, c2)
+    if (k3 < RT_INF) stk.push(c3, k3);
+    if (k2 < RT_INF) stk.push(c2, k2);
+    if (k1 < RT_INF) stk.push(c1, k1);
+    *next = c0;
+    return k0 < RT_INF;
+}
+
+// One leaf for one ray. Shadow mode returns true at the first occluder.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool leaf_step(const SceneView& sv, uint32_t cur, uint32_t obj_index, rt_f3 o, rt_f3 d,
+                                          float& closest, uint32_t& local_best, HitD& hit, LaneStats& st) {
+    const uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+    const uint32_t n = (cur & 7u) + 1u;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float4* r = sv.recs + 3 * (size_t)(first + i);
+        const float4 ra = r[0], rb = r[1], rc = r[2];
+        const rt_f3 v0 = f3(ra.x, ra.y, ra.z);
+        const rt_f3 e1 = f3(ra.w, rb.x, rb.y);
+        const rt_f3 e2 = f3(rb.z, rb.w, rc.x);
+        const uint32_t id = __float_as_uint(rc.y);
+        if (STATS) {
+            st.tri += 1;
+            st.bytes += 48;
+        }
+        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+        if (ANY) {
+            if (!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) return true;
+        } else {
+            const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
+            if (!ev.failed && ev.t > 0.0f && better) {
+                closest = ev.t;
+                local_best = id;
+                hit.tri = id;
+                hit.obj = obj_index;
+                hit.t = ev.t;
+                hit.u = ev.u;
+                hit.v = ev.v;
+            }
+        }
+    }
+    return false;
+}
+
+template <bool ANY, bool STATS, class Stack>
+__device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, uint32_t obj_index, rt_f3 o,
+                                           rt_f3 d, rt_f3 inv, float& closest, HitD& hit, Stack& stk,
+                                           LaneStats& st) {
+    const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
+    uint32_t local_best = 0;
+    stk.sp = 0;
+    uint32_t cur = root;
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            uint32_t next;
+            if (node_step<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next)) {
+                cur = next;
                 continue;
             }
         } else {
-            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
-            const uint32_t n = (cur & 7u) + 1u;
-            for (uint32_t i = 0; i < n; ++i) {
-                const float4* r = sv.recs + 3 * (size_t)(first + i);
-                const float4 ra = r[0], rb = r[1], rc = r[2];
-                const rt_f3 v0 = f3(ra.x, ra.y, ra.z);
-                const rt_f3 e1 = f3(ra.w, rb.x, rb.y);
-                const rt_f3 e2 = f3(rb.z, rb.w, rc.x);
-                const uint32_t id = __float_as_uint(rc.y);
-                if (STATS) {
-                    st.tri += 1;
-                    st.bytes += 48;
-                }
-                const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
-                if (ANY) {
-                    if (!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) return true;
-                } else {
-                    const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
-                    if (!ev.failed && ev.t > 0.0f && better) {
-                        closest = ev.t;
-                        local_best = id;
-                        hit.tri = id;
-                        hit.obj = obj_index;
-                        hit.t = ev.t;
-                        hit.u = ev.u;
-                        hit.v = ev.v;
-                    }
-                }
-            }
+            if (leaf_step<ANY, STATS>(sv, cur, obj_index, o, d, closest, local_best, hit, st)) return true;
         }
         // Next pending node whose entry distance is not beyond the current nearest hit.
         for (;;) {
@@ -892,6 +916,172 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
     out[i] = o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent per-lane walk for rays that share nothing: a wave keeps running and hands a new ray
+// to a lane as soon as its ray is finished. The lengths of incoherent rays differ widely (in a
+// triangle soup the longest of 64 runs about five times the mean), so a wave that takes 64 rays and
+// waits for the last one leaves most lanes idle most of the time.
+// The walk of closest_all is kept as a per-lane state machine: `walking` lanes take one node or one
+// leaf per turn; the others move to the next object whose box their ray meets (after the trailing
+// triangles of the one they leave), or deliver their result and become idle. Ray indices are taken
+// from a global counter, RT_REFILL or more at a time; the loop ends when the counter has passed the
+// last ray and no lane holds one.
+// Source: bool init(j, o, d) gives ray j (false: there is none, and the source has stored whatever
+// stands for it), void emit(j, hit, o, d) stores its result.
+// ---------------------------------------------------------------------------------------------
+#define RT_WALK_LDS 8
+#define RT_REFILL 16
+using WalkStack = LaneStackT<RT_WALK_LDS, 64>;
+
+template <bool STATS, class Source>
+__device__ __forceinline__ void persistent_closest(const SceneView& sv, uint32_t n_rays, uint32_t* counter,
+                                                   const Source& src, uint2* s_stack, LaneStats& st) {
+    const uint32_t lane = threadIdx.x & 63u;
+    WalkStack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    stk.sp = 0;
+    bool has = false, walking = false, in_obj = false;
+    bool exhausted = false;  // wave-uniform: the counter has passed the last ray
+    uint32_t j = 0, oi = 0, cur = 0, local_best = 0;
+    rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 1.0f), inv = d;
+    float nox = 0.0f, noy = 0.0f, noz = 0.0f, closest = RT_INF;
+    HitD hit;
+    hit.tri = RT_MISS;
+    hit.obj = 0;
+    hit.t = hit.u = hit.v = 0.0f;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (!exhausted && n_idle >= RT_REFILL) {
+            const int first = __builtin_ctzll(idle);
+            uint32_t base = 0;
+            if ((int)lane == first) base = atomicAdd(counter, n_idle);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+            exhausted = base + n_idle >= n_rays || base + n_idle < base;
+            const uint32_t idx = base + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+            if (!has && idx < n_rays && idx >= base) {
+                j = idx;
+                if (src.init(j, o, d)) {
+                    has = true;
+                    walking = false;
+                    in_obj = false;
+                    oi = 0;
+                    inv = g_recip(d);
+                    nox = -(o.x * inv.x);
+                    noy = -(o.y * inv.y);
+                    noz = -(o.z * inv.z);
+                    closest = RT_INF;
+                    hit.tri = RT_MISS;
+                    hit.obj = 0;
+                    hit.t = hit.u = hit.v = 0.0f;
+                    if (STATS) st.rays += 1;
+                }
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (has && !walking) {
+            // Leave the current object (its trailing n % 8 triangles, src/main.rs:157-169: scalar
+            // arithmetic, `closest` is not lowered, the last qualifying one wins), then find the
+            // next object whose box the ray meets.
+            if (in_obj) {
+                const DevObject& ob = sv.objs[oi];
+                for (uint32_t r = 0; r < ob.n_rest; ++r) {
+                    const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
+                    float t, u, v;
+                    if (STATS) st.tri += 1;
+                    if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, closest, &t, &u, &v)) {
+                        if (closest > t) {
+                            hit.tri = ob.tri_base + ob.n_tris - ob.n_rest + r;
+                            hit.obj = oi;
+                            hit.t = t;
+                            hit.u = u;
+                            hit.v = v;
+                        }
+                    }
+                }
+                in_obj = false;
+                ++oi;
+            }
+            while (oi < sv.n_objs) {
+                const DevObject& ob = sv.objs[oi];
+                if (STATS) st.box += 1;
+                if (box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) break;
+                ++oi;
+            }
+            if (oi < sv.n_objs) {
+                in_obj = true;
+                const uint32_t root = sv.objs[oi].root;
+                if (root != EMPTY) {
+                    walking = true;
+                    cur = root;
+                    local_best = 0;
+                    stk.sp = 0;
+                }
+            } else {
+                hit.closest = closest;
+                src.emit(j, hit, o, d);
+                has = false;
+            }
+        }
+        if (has && walking) {
+            bool need_pop = true;
+            if (!(cur & LEAF_BIT)) {
+                uint32_t next;
+                if (node_step<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next)) {
+                    cur = next;
+                    need_pop = false;
+                }
+            } else {
+                leaf_step<false, STATS>(sv, cur, oi, o, d, closest, local_best, hit, st);
+            }
+            if (need_pop) {
+                // Next pending node whose entry distance is not beyond the current nearest hit.
+                walking = false;
+                while (stk.sp != 0) {
+                    const uint2 e = stk.pop();
+                    if (!(__uint_as_float(e.y) > closest)) {
+                        cur = e.x;
+                        walking = true;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Rays of a batch call.
+struct BatchSource {
+    const rt_ray* rays;
+    rt_hit* out;
+    __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
+        const rt_ray r = rays[j];
+        o = f3(r.o[0], r.o[1], r.o[2]);
+        d = f3(r.d[0], r.d[1], r.d[2]);
+        return true;
+    }
+    __device__ __forceinline__ void emit(uint32_t j, const HitD& h, rt_f3, rt_f3) const {
+        rt_hit r;
+        r.tri = h.tri;
+        r.t = h.t;
+        r.u = h.u;
+        r.v = h.v;
+        out[j] = r;
+    }
+};
+
+__global__ __launch_bounds__(64, 8) void k_trace_closest_persistent(SceneView sv, const rt_ray* __restrict__ rays,
+                                                                   uint32_t n, uint32_t* __restrict__ counter,
+                                                                   rt_hit* __restrict__ out) {
+    __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    LaneStats st;
+    const BatchSource src{rays, out};
+    persistent_closest<false>(sv, n, counter, src, s_stack, st);
+}
+
 // The same search with the wave-coherent walks (beam where the wave's rays form one, mask walk
 // otherwise): for batches whose consecutive rays are neighbours.
 __global__ __launch_bounds__(64, 8) void k_trace_closest_wave(SceneView sv, const rt_ray* __restrict__ rays, uint64_t n,
@@ -1552,52 +1742,64 @@ struct SlotMap {
     }
 };
 
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp,
-                                                                       const uint32_t* __restrict__ tile_list,
-                                                                       uint32_t n_rays,
-                                                                       const float4* __restrict__ samp,
-                                                                       const uint32_t* __restrict__ state,
-                                                                       float4* __restrict__ dsamp,
-                                                                       uint32_t* __restrict__ dstate,
-                                                                       uint32_t* __restrict__ dkeys,
-                                                                       uint32_t* __restrict__ dvals,
-                                                                       DevStats* __restrict__ stats) {
-    __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const bool act = j < n_rays;
-    LaneStack stk;
-    stk.lds = &s_stack[threadIdx.x];
-    LaneStats st;
-    const uint32_t slot = j / p.diffuse_scatt, k = j % p.diffuse_scatt;
-    const uint32_t stt = act ? state[slot] : 0u;
-    uint32_t out_state = 0, key = 0xFFFFFFFFu;
-    float4 out = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS));
-    if (stt & RT_ST_HIT) {
-        const SlotMap sm(p, tile_list, slot);
-        const float4 a = samp[slot];
-        const rt_f3 pos = f3(a.x, a.y, a.z);
-        const rt_f3 normal = ld3(sv.tri_data + 6 * (size_t)__float_as_uint(a.w));
-        rt_f3 tang1, tang2;
-        tangent_vectors(normal, &tang1, &tang2);
-        const rt_f3 vel = diffuse_dir(p.seed, sm.sample_index, k, normal, tang1, tang2);
-        const HitD h = closest_all<STATS>(sv, pos, vel, stk, st);
-        if (h.tri != RT_MISS) {
-            const Surface s2 = surface_of(sv, h, pos, vel);
-            const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-            const rt_f3 sun_dir = g_normalize(sun - s2.pos);
-            const bool lit = g_dot(s2.normal, sun_dir) > 0.0f;
-            out = make_float4(s2.pos.x, s2.pos.y, s2.pos.z, __uint_as_float(h.tri));
-            out_state = RT_ST_HIT | (lit ? RT_ST_LIT : 0u) | (h.obj << 8);
-            if (lit) key = light_key(lp, s2.pos);
-        }
-    }
-    if (act) {
+// Scatter ray j of a launch: origin and normal from its sample's stored hit, direction k = j % scatt.
+struct BounceSource {
+    const SceneView& sv;
+    const DevRenderParams& p;
+    const LightProj& lp;
+    const uint32_t* tile_list;
+    const float4* samp;
+    const uint32_t* state;
+    float4* dsamp;
+    uint32_t* dstate;
+    uint32_t* dkeys;
+    uint32_t* dvals;
+    __device__ __forceinline__ void store(uint32_t j, float4 out, uint32_t out_state, uint32_t key) const {
         dsamp[j] = out;
         dstate[j] = out_state;
         dkeys[j] = key;
         dvals[j] = j;
     }
+    __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
+        const uint32_t slot = j / p.diffuse_scatt, k = j % p.diffuse_scatt;
+        if (!(state[slot] & RT_ST_HIT)) {
+            store(j, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS)), 0u, 0xFFFFFFFFu);
+            return false;
+        }
+        const SlotMap sm(p, tile_list, slot);
+        const float4 a = samp[slot];
+        const rt_f3 normal = ld3(sv.tri_data + 6 * (size_t)__float_as_uint(a.w));
+        rt_f3 tang1, tang2;
+        tangent_vectors(normal, &tang1, &tang2);
+        o = f3(a.x, a.y, a.z);
+        d = diffuse_dir(p.seed, sm.sample_index, k, normal, tang1, tang2);
+        return true;
+    }
+    __device__ __forceinline__ void emit(uint32_t j, const HitD& h, rt_f3 o, rt_f3 d) const {
+        if (h.tri == RT_MISS) {
+            store(j, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS)), 0u, 0xFFFFFFFFu);
+            return;
+        }
+        const Surface s2 = surface_of(sv, h, o, d);
+        const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+        const rt_f3 sun_dir = g_normalize(sun - s2.pos);
+        const bool lit = g_dot(s2.normal, sun_dir) > 0.0f;
+        store(j, make_float4(s2.pos.x, s2.pos.y, s2.pos.z, __uint_as_float(h.tri)),
+              RT_ST_HIT | (lit ? RT_ST_LIT : 0u) | (h.obj << 8), lit ? light_key(lp, s2.pos) : 0xFFFFFFFFu);
+    }
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(64, 8) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp,
+                                                    const uint32_t* __restrict__ tile_list, uint32_t n_rays,
+                                                    uint32_t* __restrict__ counter, const float4* __restrict__ samp,
+                                                    const uint32_t* __restrict__ state, float4* __restrict__ dsamp,
+                                                    uint32_t* __restrict__ dstate, uint32_t* __restrict__ dkeys,
+                                                    uint32_t* __restrict__ dvals, DevStats* __restrict__ stats) {
+    __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    LaneStats st;
+    const BounceSource src{sv, p, lp, tile_list, samp, state, dsamp, dstate, dkeys, dvals};
+    persistent_closest<STATS>(sv, n_rays, counter, src, s_stack, st);
     if (STATS) flush_stats(st, stats);
 }
 
@@ -1703,10 +1905,23 @@ namespace rtk {
 
 static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, hipStream_t s) {
+// Waves a persistent launch starts: every wave slot of the device (256 CUs x 32), or fewer for a
+// small batch.
+static inline unsigned persistent_grid(uint64_t n) { return (unsigned)std::min<uint64_t>(8192, (n + 63) / 64); }
+
+hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, uint32_t* d_counter,
+                         hipStream_t s) {
     if (n == 0) return hipSuccess;
-    static const bool wave_walk = std::getenv("RAYS_HIP_TRACE_WAVE") != nullptr;
-    if (wave_walk)
+    // RAYS_HIP_TRACE = lane: one ray per lane to the end; wave: wave-coherent walks; default: the
+    // persistent per-lane walk.
+    static const int walk = [] {
+        const char* e = std::getenv("RAYS_HIP_TRACE");
+        return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'w' ? 2 : 0));
+    }();
+    if (walk == 0 && d_counter && n < 0xFFFF0000ull)
+        hipLaunchKernelGGL(k_trace_closest_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
+                           d_counter, d_out);
+    else if (walk == 2)
         hipLaunchKernelGGL(k_trace_closest_wave, dim3(grid_for(n, 64)), dim3(64), (size_t)RT_BEAM_LEVELS * 64 * 8, s, sv,
                            d_rays, n, (uint32_t)RT_BEAM_LEVELS, d_out);
     else
@@ -1811,15 +2026,16 @@ hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint3
 }
 
 hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                     uint32_t n_rays, const float4* d_samp, const uint32_t* d_state, float4* d_dsamp, uint32_t* d_dstate,
-                     uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats, hipStream_t s) {
+                     uint32_t n_rays, uint32_t* d_counter, const float4* d_samp, const uint32_t* d_state,
+                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats,
+                     hipStream_t s) {
     if (n_rays == 0) return hipSuccess;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_bounce<true>), dim3(grid_for(n_rays, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, p, lp,
-                           d_tile_list, n_rays, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
+        hipLaunchKernelGGL((k_wf_bounce<true>), dim3(persistent_grid(n_rays)), dim3(64), 0, s, sv, p, lp, d_tile_list,
+                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_bounce<false>), dim3(grid_for(n_rays, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, p, lp,
-                           d_tile_list, n_rays, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
+        hipLaunchKernelGGL((k_wf_bounce<false>), dim3(persistent_grid(n_rays)), dim3(64), 0, s, sv, p, lp, d_tile_list,
+                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
     return hipGetLastError();
 }
 
