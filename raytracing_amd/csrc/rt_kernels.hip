@@ -929,8 +929,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // Source: bool init(j, o, d) gives ray j (false: there is none, and the source has stored whatever
 // stands for it), void emit(j, hit, o, d) stores its result.
 // ---------------------------------------------------------------------------------------------
+#ifndef RT_WALK_LDS
 #define RT_WALK_LDS 8
+#endif
+#ifndef RT_REFILL
 #define RT_REFILL 16
+#endif
+#ifndef RT_WALK_WAVES
+#define RT_WALK_WAVES 8
+#endif
 using WalkStack = LaneStackT<RT_WALK_LDS, 64>;
 
 template <bool STATS, class Source>
@@ -1073,7 +1080,7 @@ struct BatchSource {
     }
 };
 
-__global__ __launch_bounds__(64, 8) void k_trace_closest_persistent(SceneView sv, const rt_ray* __restrict__ rays,
+__global__ __launch_bounds__(64, RT_WALK_WAVES) void k_trace_closest_persistent(SceneView sv, const rt_ray* __restrict__ rays,
                                                                    uint32_t n, uint32_t* __restrict__ counter,
                                                                    rt_hit* __restrict__ out) {
     __shared__ uint2 s_stack[RT_WALK_LDS * 64];
@@ -1790,7 +1797,7 @@ struct BounceSource {
 };
 
 template <bool STATS>
-__global__ __launch_bounds__(64, 8) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp,
+__global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp,
                                                     const uint32_t* __restrict__ tile_list, uint32_t n_rays,
                                                     uint32_t* __restrict__ counter, const float4* __restrict__ samp,
                                                     const uint32_t* __restrict__ state, float4* __restrict__ dsamp,
