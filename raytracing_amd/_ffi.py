@@ -16,6 +16,7 @@ HOST_LIB = os.path.join(LIB_DIR, "librays_host.so")
 
 RT_MISS = 0xFFFFFFFF
 RT_TILE = 32
+RT_BUILD_DEVICE = 1
 
 
 class RaysError(RuntimeError):
@@ -76,6 +77,7 @@ SYMBOLS = {
     "rt_ctx_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)]),
     "rt_ctx_destroy": (None, [_VP]),
     "rt_scene_build": (C.c_int, [_VP, C.POINTER(rt_object_desc), C.c_uint32, C.POINTER(_VP)]),
+    "rt_scene_build_ex": (C.c_int, [_VP, C.POINTER(rt_object_desc), C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "rt_scene_destroy": (None, [_VP]),
     "rt_scene_num_tris": (C.c_uint32, [_VP]),
     "rt_scene_sizes": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
@@ -209,14 +211,17 @@ class Context:
 class Scene:
     """rt_scene: the packed World on one GPU."""
 
-    def __init__(self, ctx, objects):
+    def __init__(self, ctx, objects, device_build=False):
         self.ctx = ctx
         self.lib = ctx.lib
         self.n_objs = len(objects)
         self.obj_tris = [len(np.asarray(o["tris"]).reshape(-1, 3)) for o in objects]
         descs, keep = make_descs(objects)
         self.handle = _VP()
-        check(self.lib.rt_scene_build(ctx.handle, descs, len(objects), C.byref(self.handle)))
+        if device_build:
+            check(self.lib.rt_scene_build_ex(ctx.handle, descs, len(objects), RT_BUILD_DEVICE, C.byref(self.handle)))
+        else:
+            check(self.lib.rt_scene_build(ctx.handle, descs, len(objects), C.byref(self.handle)))
         del keep
 
     def close(self):

@@ -422,7 +422,12 @@ void rt_ctx_destroy(rt_ctx* c) {
 }
 
 int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_scene** out) {
+    return rt_scene_build_ex(ctx, objs, n_objs, 0u, out);
+}
+
+int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, uint32_t flags, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "out is null");
+    if (flags & ~(uint32_t)RT_BUILD_DEVICE) return fail(RT_ERR_INVALID, "unknown build flags %#x", flags);
     *out = nullptr;
     if (!ctx || !objs || n_objs == 0) return fail(RT_ERR_INVALID, "ctx / objs null or no objects");
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -525,7 +530,33 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
     const int nt = host_threads();
     uint32_t wide_width = 64;
     if (const char* e = std::getenv("RAYS_HIP_WIDE")) wide_width = (uint32_t)std::atoi(e);
-    for (uint32_t o = 0; o < n_objs; ++o) {
+    // RT_BUILD_DEVICE (or RAYS_HIP_BUILD=device): the trees are built on the device after the upload.
+    bool device_build = (flags & RT_BUILD_DEVICE) != 0u;
+    if (const char* e = std::getenv("RAYS_HIP_BUILD")) device_build = device_build || std::strcmp(e, "device") == 0;
+    struct TreeSlot {
+        uint32_t node_base = 0, wide_base = 0, rec_base = 0, n = 0;
+    };
+    std::vector<TreeSlot> slots(n_objs);
+    size_t n_nodes_total = 0, n_wide_total = 0, n_recs_total = 0;
+    uint32_t n_tree_max = 0;
+    for (uint32_t o = 0; device_build && o < n_objs; ++o) {
+        const uint32_t n_packed = (s->objects[o].n_tris / 8) * 8;
+        if (n_packed == 0) continue;
+        const rtk::LbvhLayout L = rtk::lbvh_layout(n_packed, std::min(std::max(wide_width, 2u), rtbvh::MAX_WIDE));
+        slots[o].node_base = (uint32_t)n_nodes_total;
+        slots[o].wide_base = (uint32_t)n_wide_total;
+        slots[o].rec_base = (uint32_t)n_recs_total;
+        slots[o].n = n_packed;
+        n_nodes_total += L.n_nodes4;
+        n_wide_total += L.n_wide;
+        n_recs_total += n_packed;
+        n_tree_max = std::max(n_tree_max, n_packed);
+        s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);
+        s->wide_depth = std::max(s->wide_depth, L.depth_wide);
+        if (n_wide_total >= (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+    }
+    if (s->max_stack > RT_STACK_MAX || s->wide_depth > RT_BEAM_LEVELS) return fail(RT_ERR_UNSUPPORTED, "tree too deep");
+    for (uint32_t o = 0; !device_build && o < n_objs; ++o) {
         DevObject& ob = s->objects[o];
         const uint32_t n_packed = (ob.n_tris / 8) * 8;
         if (n_packed == 0) continue;
@@ -557,17 +588,23 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         nodes_all.insert(nodes_all.end(), res.nodes.begin(), res.nodes.end());
         for (uint32_t r : res.order) order_all.push_back(ob.tri_base + r);
     }
-    s->n_nodes = (uint32_t)nodes_all.size();
-    s->sizes[0] = wide_all.size() * sizeof(rtbvh::Child);
-    s->sizes[1] = nodes_all.size() * sizeof(rtbvh::Node4);
-    s->sizes[2] = order_all.size() * 48;
+    if (!device_build) {
+        n_nodes_total = nodes_all.size();
+        n_wide_total = wide_all.size();
+        n_recs_total = order_all.size();
+    }
+    s->n_nodes = (uint32_t)n_nodes_total;
+    s->sizes[0] = n_wide_total * sizeof(rtbvh::Child);
+    s->sizes[1] = n_nodes_total * sizeof(rtbvh::Node4);
+    s->sizes[2] = n_recs_total * 48;
     s->sizes[3] = (uint64_t)s->n_tris * 24;
     {
+        auto has_tree = [](const DevObject& ob) { return ob.n_tris >= 8u; };
         bool any_tree = false;
-        for (const DevObject& ob : s->objects) any_tree = any_tree || ob.root != rtbvh::EMPTY;
+        for (const DevObject& ob : s->objects) any_tree = any_tree || has_tree(ob);
         bool first = true;
         for (const DevObject& ob : s->objects) {
-            if (any_tree && ob.root == rtbvh::EMPTY) continue;
+            if (any_tree && !has_tree(ob)) continue;
             for (int k = 0; k < 3; ++k) {
                 s->bounds_lo[k] = first ? ob.bbmin[k] : std::min(s->bounds_lo[k], ob.bbmin[k]);
                 s->bounds_hi[k] = first ? ob.bbmax[k] : std::max(s->bounds_hi[k], ob.bbmax[k]);
@@ -576,8 +613,9 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         }
     }
     if (std::getenv("RAYS_HIP_VERBOSE"))
-        std::fprintf(stderr, "[rays_hip] %u tris, %zu nodes4 (stack bound %u), wide width %u: %zu children, depth %u\n",
-                     s->n_tris, nodes_all.size(), s->max_stack, wide_width, wide_all.size(), s->wide_depth);
+        std::fprintf(stderr, "[rays_hip] %u tris, %zu nodes4 (stack bound %u), wide width %u: %zu children, depth %u%s\n",
+                     s->n_tris, n_nodes_total, s->max_stack, wide_width, n_wide_total, s->wide_depth,
+                     device_build ? " (device build)" : "");
 
     // ---- upload and pack on the device -----------------------------------------------------
     DevPool pool;
@@ -591,14 +629,14 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
     HIP_TRY(tmp.alloc((void**)&d_verts, verts_all.size() * 4));
     HIP_TRY(tmp.alloc((void**)&d_tris, tris_all.size() * 4));
     HIP_TRY(tmp.alloc((void**)&d_leaf_first, leaf_first.size() * 4));
-    HIP_TRY(tmp.alloc((void**)&d_order, order_all.size() * 4));
+    HIP_TRY(tmp.alloc((void**)&d_order, n_recs_total * 4));
     HIP_TRY(pool.alloc((void**)&d_tri9, (size_t)total_tris * 36));
     HIP_TRY(pool.alloc((void**)&d_leaf_bounds, leaf_first.size() * 24));
     HIP_TRY(pool.alloc((void**)&d_data, data_all.size() * 4));
     HIP_TRY(pool.alloc((void**)&d_rest, rest_verts.size() * 4));
-    HIP_TRY(pool.alloc((void**)&d_recs, order_all.size() * 48 + 192));  // padded: a leaf is read as 192 B
-    HIP_TRY(pool.alloc((void**)&d_nodes, nodes_all.size() * sizeof(rtbvh::Node4)));
-    HIP_TRY(pool.alloc((void**)&d_wide, wide_all.size() * sizeof(rtbvh::Child)));
+    HIP_TRY(pool.alloc((void**)&d_recs, n_recs_total * 48 + 192));  // padded: a leaf is read as 192 B
+    HIP_TRY(pool.alloc((void**)&d_nodes, n_nodes_total * sizeof(rtbvh::Node4)));
+    HIP_TRY(pool.alloc((void**)&d_wide, n_wide_total * sizeof(rtbvh::Child)));
     HIP_TRY(pool.alloc((void**)&d_objs, s->objects.size() * sizeof(DevObject)));
     HIP_TRY(hipMemcpy(d_verts, verts_all.data(), verts_all.size() * 4, hipMemcpyHostToDevice));
     if (!tris_all.empty()) HIP_TRY(hipMemcpy(d_tris, tris_all.data(), tris_all.size() * 4, hipMemcpyHostToDevice));
@@ -613,10 +651,29 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
         HIP_TRY(hipMemcpy(d_nodes, nodes_all.data(), nodes_all.size() * sizeof(rtbvh::Node4), hipMemcpyHostToDevice));
     if (!wide_all.empty())
         HIP_TRY(hipMemcpy(d_wide, wide_all.data(), wide_all.size() * sizeof(rtbvh::Child), hipMemcpyHostToDevice));
+    if (device_build && n_tree_max > 0) {
+        uint32_t *keys[2], *vals[2];
+        void* sort_tmp;
+        size_t tb = 0;
+        HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n_tree_max, 32, 0));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(tmp.alloc((void**)&keys[k], (size_t)n_tree_max * 4));
+            HIP_TRY(tmp.alloc((void**)&vals[k], (size_t)n_tree_max * 4));
+        }
+        HIP_TRY(tmp.alloc(&sort_tmp, std::max<size_t>(tb, 16)));
+        for (uint32_t o = 0; o < n_objs; ++o) {
+            if (slots[o].n == 0) continue;
+            DevObject& ob = s->objects[o];
+            HIP_TRY(rtk::lbvh_build(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, ob.bbmin, ob.bbmax, ob.tri_base,
+                                    slots[o].rec_base, slots[o].node_base, slots[o].wide_base,
+                                    std::min(std::max(wide_width, 2u), rtbvh::MAX_WIDE), d_nodes, d_wide, d_order, keys,
+                                    vals, sort_tmp, tb, &ob.root, &ob.wide_root, 0));
+        }
+    }
     HIP_TRY(hipMemcpy(d_objs, s->objects.data(), s->objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
     HIP_TRY(rtk::pack_tris(d_verts, d_tris, (uint32_t)total_tris, d_tri9, 0));
     HIP_TRY(rtk::leaf_bounds(d_verts, d_tris, d_leaf_first, (uint32_t)leaf_first.size(), d_leaf_bounds, 0));
-    HIP_TRY(rtk::gather_records(d_tri9, d_order, (uint32_t)order_all.size(), d_recs, 0));
+    HIP_TRY(rtk::gather_records(d_tri9, d_order, (uint32_t)n_recs_total, d_recs, 0));
     HIP_TRY(hipDeviceSynchronize());
 
     s->view.objs = d_objs;

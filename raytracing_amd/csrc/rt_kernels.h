@@ -45,6 +45,22 @@ hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, con
 // temp == nullptr only *temp_bytes is set.
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                           const uint32_t* vals_in, uint32_t* vals_out, size_t n, unsigned key_bits, hipStream_t s);
+// Tree build on the device (rt_lbvh.hip). Sizes of the two trees over n single-triangle leaves:
+struct LbvhLayout {
+    uint32_t n_nodes4, depth4;     // 4-wide tree: nodes, levels
+    uint32_t n_wide, depth_wide;   // wide tree: child records (leaf level included), node levels
+    uint32_t top_count;            // children of the wide root
+};
+LbvhLayout lbvh_layout(uint32_t n, uint32_t fan);
+// Builds both trees of one object over triangles d_tris[0 .. n) (three global vertex indices each)
+// into d_nodes_all + node_base, d_wide_all + wide_base and the record order into
+// d_order_all + rec_base (global triangle ids). d_keys / d_vals: two scratch arrays of n words each;
+// d_temp: sort scratch for n pairs. Returns the roots' references.
+hipError_t lbvh_build(const float* d_verts, const uint32_t* d_tris, uint32_t n, const float bbmin[3], const float bbmax[3],
+                      uint32_t tri_base, uint32_t rec_base, uint32_t node_base, uint32_t wide_base, uint32_t fan,
+                      rtbvh::Node4* d_nodes_all, rtbvh::Child* d_wide_all, uint32_t* d_order_all, uint32_t* d_keys[2],
+                      uint32_t* d_vals[2], void* d_temp, size_t temp_bytes, uint32_t* root4, uint32_t* wide_root,
+                      hipStream_t s);
 hipError_t deinterleave(const uint8_t* d_gathered, const uint32_t* d_tile_slot, uint32_t slab_tiles, uint32_t width,
                         uint32_t height, uint32_t tiles_x, uint32_t n_tiles_total, uint32_t shard_count,
                         uint8_t* d_rgba8, hipStream_t s);

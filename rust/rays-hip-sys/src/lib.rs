@@ -3,6 +3,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const RT_MISS: u32 = 0xFFFF_FFFF;
+pub const RT_BUILD_DEVICE: u32 = 1;
 pub const RT_TILE: u32 = 32;
 pub const RT_RENDER_EVENTS: c_int = 5;
 
@@ -76,6 +77,7 @@ extern "C" {
     pub fn rt_ctx_create(devices: *const c_int, n: c_int, out: *mut *mut rt_ctx) -> c_int;
     pub fn rt_ctx_destroy(ctx: *mut rt_ctx);
     pub fn rt_scene_build(ctx: *mut rt_ctx, objs: *const rt_object_desc, n_objs: u32, out: *mut *mut rt_scene) -> c_int;
+    pub fn rt_scene_build_ex(ctx: *mut rt_ctx, objs: *const rt_object_desc, n_objs: u32, flags: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
     pub fn rt_scene_num_tris(scene: *const rt_scene) -> u32;
     pub fn rt_scene_sizes(scene: *const rt_scene, sizes: *mut u64) -> c_int;

@@ -376,6 +376,30 @@ def test_render_soup_frame_sizes_cover_every_sort_path(soup_pair, size):
     _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
 
 
+@pytest.mark.parametrize("which", ["teapot", "soup"])
+def test_device_built_tree_gives_the_same_answers(which, ctx, oracle, default_objects, soup64k):
+    """RT_BUILD_DEVICE builds the trees on the GPU (Morton order, fixed fan-out). The structure
+    differs from the host build; every search result and the rendered frame must not."""
+    objs = default_objects if which == "teapot" else soup64k
+    g = Scene(ctx, objs, device_build=True)
+    o = oracle.OracleScene(objs)
+    rays = scenes.camera_rays(240, 136, 2)
+    _compare_hits(g.trace_closest(rays), o.trace_closest(rays), 0.0 if which == "teapot" else 1e-5)
+    rng = np.random.default_rng(7)
+    n = 20000
+    org = rng.uniform(-8, 8, (n, 3)).astype(np.float32) + np.array([0, 0, 12], dtype=np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    inc = np.concatenate([org, d], axis=1)
+    _compare_hits(g.trace_closest(inc), o.trace_closest(inc), 1e-4)
+    assert (g.trace_any(inc) != o.trace_any(inc)).mean() <= 1e-4
+    W, H = 200, 120
+    kw = dict(reflect_depth=1, diffuse_depth=1)
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
+    rgba, ids = g.render(render_params(W, H, 2, **kw), want_hit_ids=True)
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
+    g.close()
+
+
 def test_full_size_properties_soup_1m(ctx, oracle):
     """BASELINE configuration 3 at full size: 1,000,000 triangles, 3840x2160, four samples. The
     oracle cannot scan it in full in test time, so: a strided subsample is compared ray by ray, the
