@@ -1636,8 +1636,11 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     if (STATS) flush_stats(st, stats);
 }
 
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES RT_WF_WAVES
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(RT_WF_BLOCK, RT_WF_WAVES) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
+__global__ __launch_bounds__(RT_WF_BLOCK, RT_SHADOW_WAVES) void k_wf_shadow(SceneView sv, DevRenderParams p, uint32_t n,
                                                         uint32_t cell_shift,
                                                         const uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals,

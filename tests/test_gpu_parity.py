@@ -239,6 +239,17 @@ def test_render_soup_diffuse_bounce_pipeline(soup_pair, monkeypatch):
     assert np.array_equal(acc, rgba)
 
 
+@pytest.mark.parametrize("grid", [1, 4, 8])
+def test_render_other_sample_grids(soup_pair, grid):
+    """n x n sub-samples per pixel other than the reference's 2 x 2: 1, 16 and 64 samples."""
+    g, o = soup_pair
+    W, H = (160, 96) if grid < 8 else (64, 40)
+    kw = dict(reflect_depth=1, diffuse_depth=1)
+    ref_rgba, ref_ids, _ = o.render(W, H, grid, want_hit_ids=True, **kw)
+    rgba, ids = g.render(render_params(W, H, grid, **kw), want_hit_ids=True)
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, grid * grid, 1e-5)
+
+
 def test_render_sharded_tiles_cover_the_frame(teapot_pair):
     g, _ = teapot_pair
     W, H = 200, 120  # not a multiple of the tile size
