@@ -752,7 +752,12 @@ int rt_trace_any_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, uint8_t* 
     if (n == 0) return RT_OK;
     if (!d_rays || !d_occluded) return fail(RT_ERR_INVALID, "null buffer");
     if (n > (1ull << 31) * RT_BLOCK) return fail(RT_ERR_INVALID, "too many rays in one call");
-    HIP_TRY(rtk::trace_any(s->view, d_rays, n, d_occluded, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(s->ctx->mu);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    uint32_t* counter = nullptr;
+    int rc = take_counter(s->ctx, (hipStream_t)stream, &counter);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(rtk::trace_any(s->view, d_rays, n, d_occluded, counter, (hipStream_t)stream));
     return RT_OK;
 }
 
@@ -791,7 +796,9 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* out) {
 
 int rt_trace_any(rt_scene* s, const rt_ray* rays, uint64_t n, uint8_t* occluded) {
     return trace_host<uint8_t>(s, rays, n, occluded, [&](const rt_ray* dr, uint8_t* dout) {
-        return rtk::trace_any(s->view, dr, n, dout, 0);
+        uint32_t* counter = nullptr;
+        if (take_counter(s->ctx, 0, &counter) != RT_OK) return hipErrorOutOfMemory;
+        return rtk::trace_any(s->view, dr, n, dout, counter, 0);
     });
 }
 

@@ -927,7 +927,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // from a global counter, RT_REFILL or more at a time; the loop ends when the counter has passed the
 // last ray and no lane holds one.
 // Source: bool init(j, o, d) gives ray j (false: there is none, and the source has stored whatever
-// stands for it), void emit(j, hit, o, d) stores its result.
+// stands for it), void emit(j, hit, o, d) stores its result. In shadow mode (ANY) the walk ends at
+// the first occluder and hit.tri != RT_MISS says "occluded".
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_WALK_LDS
 #define RT_WALK_LDS 8
@@ -940,9 +941,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #endif
 using WalkStack = LaneStackT<RT_WALK_LDS, 64>;
 
-template <bool STATS, class Source>
-__device__ __forceinline__ void persistent_closest(const SceneView& sv, uint32_t n_rays, uint32_t* counter,
-                                                   const Source& src, uint2* s_stack, LaneStats& st) {
+template <bool ANY, bool STATS, class Source>
+__device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_rays, uint32_t* counter,
+                                                const Source& src, uint2* s_stack, LaneStats& st) {
     const uint32_t lane = threadIdx.x & 63u;
     WalkStack stk;
     stk.lds = &s_stack[threadIdx.x];
@@ -1000,6 +1001,12 @@ __device__ __forceinline__ void persistent_closest(const SceneView& sv, uint32_t
                     float t, u, v;
                     if (STATS) st.tri += 1;
                     if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, closest, &t, &u, &v)) {
+                        if (ANY) {
+                            // src/main.rs:226-231: any trailing triangle that qualifies occludes.
+                            hit.tri = 0;
+                            oi = sv.n_objs;
+                            break;
+                        }
                         if (closest > t) {
                             hit.tri = ob.tri_base + ob.n_tris - ob.n_rest + r;
                             hit.obj = oi;
@@ -1010,7 +1017,7 @@ __device__ __forceinline__ void persistent_closest(const SceneView& sv, uint32_t
                     }
                 }
                 in_obj = false;
-                ++oi;
+                if (oi < sv.n_objs) ++oi;
             }
             while (oi < sv.n_objs) {
                 const DevObject& ob = sv.objs[oi];
@@ -1042,7 +1049,13 @@ __device__ __forceinline__ void persistent_closest(const SceneView& sv, uint32_t
                     need_pop = false;
                 }
             } else {
-                leaf_step<false, STATS>(sv, cur, oi, o, d, closest, local_best, hit, st);
+                if (leaf_step<ANY, STATS>(sv, cur, oi, o, d, closest, local_best, hit, st)) {
+                    // Shadow mode: occluded; the ray is finished (hit.tri != RT_MISS marks it).
+                    hit.tri = 0;
+                    stk.sp = 0;
+                    in_obj = false;
+                    oi = sv.n_objs;
+                }
             }
             if (need_pop) {
                 // Next pending node whose entry distance is not beyond the current nearest hit.
@@ -1080,13 +1093,36 @@ struct BatchSource {
     }
 };
 
+struct BatchAnySource {
+    const rt_ray* rays;
+    uint8_t* out;
+    __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
+        const rt_ray r = rays[j];
+        o = f3(r.o[0], r.o[1], r.o[2]);
+        d = f3(r.d[0], r.d[1], r.d[2]);
+        return true;
+    }
+    __device__ __forceinline__ void emit(uint32_t j, const HitD& h, rt_f3, rt_f3) const {
+        out[j] = h.tri != RT_MISS ? 1 : 0;
+    }
+};
+
+__global__ __launch_bounds__(64, RT_WALK_WAVES) void k_trace_any_persistent(SceneView sv, const rt_ray* __restrict__ rays,
+                                                                           uint32_t n, uint32_t* __restrict__ counter,
+                                                                           uint8_t* __restrict__ out) {
+    __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    LaneStats st;
+    const BatchAnySource src{rays, out};
+    persistent_walk<true, false>(sv, n, counter, src, s_stack, st);
+}
+
 __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_trace_closest_persistent(SceneView sv, const rt_ray* __restrict__ rays,
                                                                    uint32_t n, uint32_t* __restrict__ counter,
                                                                    rt_hit* __restrict__ out) {
     __shared__ uint2 s_stack[RT_WALK_LDS * 64];
     LaneStats st;
     const BatchSource src{rays, out};
-    persistent_closest<false>(sv, n, counter, src, s_stack, st);
+    persistent_walk<false, false>(sv, n, counter, src, s_stack, st);
 }
 
 // The same search with the wave-coherent walks (beam where the wave's rays form one, mask walk
@@ -1809,7 +1845,7 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
     __shared__ uint2 s_stack[RT_WALK_LDS * 64];
     LaneStats st;
     const BounceSource src{sv, p, lp, tile_list, samp, state, dsamp, dstate, dkeys, dvals};
-    persistent_closest<STATS>(sv, n_rays, counter, src, s_stack, st);
+    persistent_walk<false, STATS>(sv, n_rays, counter, src, s_stack, st);
     if (STATS) flush_stats(st, stats);
 }
 
@@ -1939,9 +1975,18 @@ hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, 
     return hipGetLastError();
 }
 
-hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, hipStream_t s) {
+hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, uint32_t* d_counter,
+                     hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_occ);
+    static const bool lane_walk = [] {
+        const char* e = std::getenv("RAYS_HIP_TRACE");
+        return e && e[0] == 'l';
+    }();
+    if (!lane_walk && d_counter && n < 0xFFFF0000ull)
+        hipLaunchKernelGGL(k_trace_any_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
+                           d_counter, d_occ);
+    else
+        hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_occ);
     return hipGetLastError();
 }
 
