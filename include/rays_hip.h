@@ -112,8 +112,9 @@ void rt_ctx_destroy(rt_ctx*);
  * uploads it. */
 int  rt_scene_build(rt_ctx*, const rt_object_desc* objs, uint32_t n_objs, rt_scene** out);
 /* As rt_scene_build, with flags. RT_BUILD_DEVICE: the traversal structure is built on the GPU
- * (triangles in Morton order, fixed fan-out): a build of milliseconds instead of seconds for
- * millions of triangles, with looser boxes and therefore slower searches. Results are the same:
+ * (triangles in Morton order, a binary radix tree collapsed to the walks' node widths): a build of
+ * milliseconds instead of seconds for millions of triangles, with looser boxes and therefore somewhat
+ * slower searches. Results are the same:
  * the nearest hit does not depend on the structure. No reference counterpart (the reference has no
  * tree, src/opt.rs:38-80 only packs leaves). */
 #define RT_BUILD_DEVICE 1u

@@ -539,21 +539,30 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     std::vector<TreeSlot> slots(n_objs);
     size_t n_nodes_total = 0, n_wide_total = 0, n_recs_total = 0;
     uint32_t n_tree_max = 0;
+    // Two device builders: cuts where the sorted Morton codes first differ (a binary radix tree,
+    // collapsed top-down; the default) or every 4 / 64 records of the Morton curve (RAYS_HIP_LBVH=chunk,
+    // and the fallback when the radix tree comes out too deep). The first needs room for n 4-wide
+    // nodes and 2 n wide child records per object; what it uses is known after the build.
+    bool chunked = false;
+    if (const char* e = std::getenv("RAYS_HIP_LBVH")) chunked = std::strcmp(e, "chunk") == 0;
+    const uint32_t fan = std::min(std::max(wide_width, 2u), rtbvh::MAX_WIDE);
     for (uint32_t o = 0; device_build && o < n_objs; ++o) {
         const uint32_t n_packed = (s->objects[o].n_tris / 8) * 8;
         if (n_packed == 0) continue;
-        const rtk::LbvhLayout L = rtk::lbvh_layout(n_packed, std::min(std::max(wide_width, 2u), rtbvh::MAX_WIDE));
+        const rtk::LbvhLayout L = rtk::lbvh_layout(n_packed, fan);
         slots[o].node_base = (uint32_t)n_nodes_total;
         slots[o].wide_base = (uint32_t)n_wide_total;
         slots[o].rec_base = (uint32_t)n_recs_total;
         slots[o].n = n_packed;
-        n_nodes_total += L.n_nodes4;
-        n_wide_total += L.n_wide;
+        n_nodes_total += chunked ? L.n_nodes4 : n_packed;
+        n_wide_total += chunked ? L.n_wide : 2 * (size_t)n_packed;
         n_recs_total += n_packed;
         n_tree_max = std::max(n_tree_max, n_packed);
-        s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);
-        s->wide_depth = std::max(s->wide_depth, L.depth_wide);
-        if (n_wide_total >= (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+        if (chunked) {
+            s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);
+            s->wide_depth = std::max(s->wide_depth, L.depth_wide);
+        }
+        if (n_wide_total >= (1u << 26)) return fail(RT_ERR_UNSUPPORTED, "wide tree too large");
     }
     if (s->max_stack > RT_STACK_MAX || s->wide_depth > RT_BEAM_LEVELS) return fail(RT_ERR_UNSUPPORTED, "tree too deep");
     for (uint32_t o = 0; !device_build && o < n_objs; ++o) {
@@ -661,14 +670,44 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             HIP_TRY(tmp.alloc((void**)&vals[k], (size_t)n_tree_max * 4));
         }
         HIP_TRY(tmp.alloc(&sort_tmp, std::max<size_t>(tb, 16)));
+        void* work = nullptr;
+        if (!chunked) HIP_TRY(tmp.alloc(&work, rtk::lbvh_radix_work_bytes(n_tree_max)));
+        size_t used_nodes = 0, used_wide = 0;
         for (uint32_t o = 0; o < n_objs; ++o) {
             if (slots[o].n == 0) continue;
             DevObject& ob = s->objects[o];
-            HIP_TRY(rtk::lbvh_build(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, ob.bbmin, ob.bbmax, ob.tri_base,
-                                    slots[o].rec_base, slots[o].node_base, slots[o].wide_base,
-                                    std::min(std::max(wide_width, 2u), rtbvh::MAX_WIDE), d_nodes, d_wide, d_order, keys,
-                                    vals, sort_tmp, tb, &ob.root, &ob.wide_root, 0));
+            bool done = false;
+            if (!chunked) {
+                rtk::LbvhResult res{};
+                HIP_TRY(rtk::lbvh_build_radix(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, ob.bbmin, ob.bbmax,
+                                              ob.tri_base, slots[o].rec_base, slots[o].node_base, slots[o].wide_base, fan,
+                                              d_nodes, d_wide, d_order, keys, vals, sort_tmp, tb, work, &res, 0));
+                if (3u * res.depth4 + 1u <= RT_STACK_MAX && res.depth_wide <= RT_BEAM_LEVELS) {
+                    ob.root = res.root4;
+                    ob.wide_root = res.wide_root;
+                    s->max_stack = std::max(s->max_stack, 3u * res.depth4 + 1u);
+                    s->wide_depth = std::max(s->wide_depth, res.depth_wide);
+                    used_nodes += res.n_nodes4;
+                    used_wide += res.n_wide;
+                    done = true;
+                }
+            }
+            if (!done) {
+                const rtk::LbvhLayout L = rtk::lbvh_layout(slots[o].n, fan);
+                HIP_TRY(rtk::lbvh_build(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, ob.bbmin, ob.bbmax,
+                                        ob.tri_base, slots[o].rec_base, slots[o].node_base, slots[o].wide_base, fan,
+                                        d_nodes, d_wide, d_order, keys, vals, sort_tmp, tb, &ob.root, &ob.wide_root, 0));
+                s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);
+                s->wide_depth = std::max(s->wide_depth, L.depth_wide);
+                used_nodes += L.n_nodes4;
+                used_wide += L.n_wide;
+            }
         }
+        s->sizes[0] = used_wide * sizeof(rtbvh::Child);
+        s->sizes[1] = used_nodes * sizeof(rtbvh::Node4);
+        if (std::getenv("RAYS_HIP_VERBOSE"))
+            std::fprintf(stderr, "[rays_hip] device build: %zu nodes4 (stack bound %u), %zu wide children, depth %u\n",
+                         used_nodes, s->max_stack, used_wide, s->wide_depth);
     }
     HIP_TRY(hipMemcpy(d_objs, s->objects.data(), s->objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
     HIP_TRY(rtk::pack_tris(d_verts, d_tris, (uint32_t)total_tris, d_tri9, 0));

@@ -62,6 +62,21 @@ hipError_t lbvh_build(const float* d_verts, const uint32_t* d_tris, uint32_t n, 
                       rtbvh::Node4* d_nodes_all, rtbvh::Child* d_wide_all, uint32_t* d_order_all, uint32_t* d_keys[2],
                       uint32_t* d_vals[2], void* d_temp, size_t temp_bytes, uint32_t* root4, uint32_t* wide_root,
                       hipStream_t s);
+// The same with cuts where the sorted Morton codes first differ (a binary radix tree), boxes fitted
+// bottom-up and both trees collapsed from it top-down. Better trees than lbvh_build; a few host
+// synchronisations per level. Needs room for n 4-wide nodes and 2 n wide child records, and
+// lbvh_radix_work_bytes(n) bytes of scratch.
+struct LbvhResult {
+    uint32_t root4, wide_root;    // references of the roots
+    uint32_t n_nodes4, n_wide;    // entries used
+    uint32_t depth4, depth_wide;  // levels
+};
+size_t lbvh_radix_work_bytes(uint32_t n);
+hipError_t lbvh_build_radix(const float* d_verts, const uint32_t* d_tris, uint32_t n, const float bbmin[3],
+                            const float bbmax[3], uint32_t tri_base, uint32_t rec_base, uint32_t node_base,
+                            uint32_t wide_base, uint32_t fan, rtbvh::Node4* d_nodes_all, rtbvh::Child* d_wide_all,
+                            uint32_t* d_order_all, uint32_t* d_keys[2], uint32_t* d_vals[2], void* d_temp,
+                            size_t temp_bytes, void* d_work, LbvhResult* out, hipStream_t s);
 hipError_t deinterleave(const uint8_t* d_gathered, const uint32_t* d_tile_slot, uint32_t slab_tiles, uint32_t width,
                         uint32_t height, uint32_t tiles_x, uint32_t n_tiles_total, uint32_t shard_count,
                         uint8_t* d_rgba8, hipStream_t s);
