@@ -253,11 +253,17 @@ struct Collapser {
     // own (f(n) = area(n) + best split of `width` slots over its two sides), or the k slots are
     // split between its two sides. Children are created after their parents, so a reverse sweep
     // over the node array is a post-order.
-    std::vector<uint32_t> dp_off;
-    std::vector<uint8_t> dp_m, dp_choice, dp_root_split;
-    std::vector<float> dp_g;
+    struct Plan {
+        std::vector<uint32_t> dp_off;
+        std::vector<uint8_t> dp_m, dp_choice, dp_root_split;
+        std::vector<float> dp_g;
+    };
+    Plan plan_wide, plan_4;
 
-    void plan(uint32_t width) {
+    void plan(uint32_t width, Plan& P) {
+        std::vector<uint32_t>& dp_off = P.dp_off;
+        std::vector<uint8_t>&dp_m = P.dp_m, &dp_choice = P.dp_choice, &dp_root_split = P.dp_root_split;
+        std::vector<float>& dp_g = P.dp_g;
         const uint32_t nn = b.used();
         n_leaves.assign(b.nodes_.size(), 0);
         dp_off.assign(nn + 1, 0);
@@ -305,16 +311,23 @@ struct Collapser {
         }
     }
 
-    void collect(uint32_t c, uint32_t k, std::vector<uint32_t>& kids) const {
+    void collect(const Plan& P, uint32_t c, uint32_t k, std::vector<uint32_t>& kids) const {
         const Node2& n = b.nodes_[c];
-        k = std::min<uint32_t>(k, dp_m[c]);
-        const uint32_t a = n.count > 0 ? 0u : dp_choice[dp_off[c] + k - 1];
+        k = std::min<uint32_t>(k, P.dp_m[c]);
+        const uint32_t a = n.count > 0 ? 0u : P.dp_choice[P.dp_off[c] + k - 1];
         if (a == 0) {
             kids.push_back(c);
             return;
         }
-        collect(n.left, a, kids);
-        collect(n.right, k - a, kids);
+        collect(P, n.left, a, kids);
+        collect(P, n.right, k - a, kids);
+    }
+    // Children of the wide (or 4-wide) node made of binary node root2, by the plan.
+    void planned_kids(Plan& P, uint32_t width, uint32_t root2, std::vector<uint32_t>& kids) {
+        if (P.dp_m.empty()) plan(width, P);
+        const uint32_t a = P.dp_root_split[root2];
+        collect(P, b.nodes_[root2].left, a, kids);
+        collect(P, b.nodes_[root2].right, P.dp_m[root2] - a, kids);
     }
 
     uint32_t emit_leaf(const Node2& n) {
@@ -332,10 +345,7 @@ struct Collapser {
         out.wide_depth = std::max(out.wide_depth, depth);
         std::vector<uint32_t> kids;
         if (collapse_rule() == 2) {
-            if (dp_m.empty()) plan(width);
-            const uint32_t a = dp_root_split[root2];
-            collect(b.nodes_[root2].left, a, kids);
-            collect(b.nodes_[root2].right, dp_m[root2] - a, kids);
+            planned_kids(plan_wide, width, root2, kids);
         } else {
             kids.push_back(b.nodes_[root2].left);
             kids.push_back(b.nodes_[root2].right);
@@ -393,10 +403,22 @@ struct Collapser {
         out.nodes.emplace_back();
         uint32_t kids[4];
         int nk = 0;
-        kids[nk++] = b.nodes_[root2].left;
-        kids[nk++] = b.nodes_[root2].right;
+        static const bool plan4 = [] {
+            const char* e = std::getenv("RAYS_HIP_COLLAPSE4");
+            return e ? std::atoi(e) == 2 : true;
+        }();
+        if (plan4) {
+            // The same least-area plan as for the wide tree: a lane's visit of a 4-wide node costs
+            // the same whatever its child count.
+            std::vector<uint32_t> pk;
+            planned_kids(plan_4, 4, root2, pk);
+            for (uint32_t k : pk) kids[nk++] = k;
+        } else {
+            kids[nk++] = b.nodes_[root2].left;
+            kids[nk++] = b.nodes_[root2].right;
+        }
         // Open the largest inner child until four slots are used.
-        while (nk < 4) {
+        while (!plan4 && nk < 4) {
             int pick = -1;
             float best = -1.0f;
             for (int i = 0; i < nk; ++i) {
