@@ -158,7 +158,9 @@ int  rt_trace_closest_linear(rt_scene*, const rt_ray* rays, uint64_t n, rt_hit* 
  * shard_count > 1 only this shard's tiles are written; the rest of the buffers is untouched. */
 int  rt_render(rt_scene*, const rt_render_params*, uint8_t* rgba8, uint32_t* hit_ids);
 /* Device-buffer form. With shard_count > 1, d_rgba8 is this shard's compact tile buffer of
- * rt_shard_tiles() tiles, each RT_TILE * RT_TILE * 4 bytes, in ascending tile id. */
+ * rt_shard_tiles() tiles, each RT_TILE * RT_TILE * 4 bytes, in ascending tile id. The frames of one
+ * scene share the scene's per-sample workspace: enqueue them on one stream, or order the streams
+ * yourself; frames of different scenes may overlap. */
 int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                       void* stream);
 /* As rt_render_device, and records the caller's hipEvent_t handles on the stream around the
