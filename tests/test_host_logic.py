@@ -278,3 +278,57 @@ def test_deinterleave_numpy_round_trip():
         x0, y0 = (t % tx) * 32, (t // tx) * 32
         g[shard[t], slot[t]] = padded[y0:y0 + 32, x0:x0 + 32]
     assert np.array_equal(rd.deinterleave_numpy(g, w, h, n), frame)
+
+
+@pytest.fixture(scope="module")
+def bvh_shim(tmp_path_factory):
+    """The product's host tree builder behind a small checking shim (tests/native/bvh_check.cpp)."""
+    import subprocess
+
+    out = tmp_path_factory.mktemp("bvh") / "libbvh_check.so"
+    csrc = os.path.join(ROOT, "raytracing_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", csrc, "-o", str(out),
+                    os.path.join(ROOT, "tests", "native", "bvh_check.cpp"), os.path.join(csrc, "bvh_build.cpp")],
+                   check=True)
+    lib = ctypes.CDLL(str(out))
+    lib.bvh_check.restype = ctypes.c_int
+    lib.bvh_check.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                              ctypes.c_void_p]
+    return lib
+
+
+def _tri_boxes(n, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "soup":
+        c = rng.uniform(-10, 10, (n, 3))
+        e = rng.uniform(0, 0.2, (n, 3))
+    elif kind == "line":        # centroids on one line: long thin splits
+        c = np.stack([np.linspace(0, 100, n), np.zeros(n), np.zeros(n)], 1)
+        e = np.full((n, 3), 0.01)
+    else:                       # "same": every box identical, no split plane exists
+        c = np.zeros((n, 3))
+        e = np.ones((n, 3))
+    return np.concatenate([c - e, c + e], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,n", [("soup", 8), ("soup", 9), ("soup", 4096), ("soup", 60000), ("line", 5000),
+                                    ("same", 700)])
+@pytest.mark.parametrize("width", [4, 32, 64])
+def test_host_tree_builder_invariants(bvh_shim, kind, n, width):
+    """Both trees hold every triangle exactly once, every box contains what is below it, nodes
+    have at most `width` children, and the reported depth and stack bound are the real ones. The
+    least-area collapse must also leave fewer wide nodes than triangles / 8 on a soup."""
+    boxes = _tri_boxes(n, 1234 + n, kind)
+    out = (ctypes.c_uint32 * 8)()
+    for balanced in (0, 1):
+        rc = bvh_shim.bvh_check(boxes.ctypes.data, n, width, 4, balanced, out)
+        assert rc == 0, f"invariant {rc} violated (kind {kind}, n {n}, width {width}, balanced {balanced})"
+        nodes4, wide_children, depth = out[0], out[1], out[2]
+        assert nodes4 >= 1 and wide_children >= n / rtb_max_leaf() and depth >= 1
+    if kind == "soup" and n >= 4096 and width == 64:
+        inner = out[1] - n   # with one triangle per leaf
+        assert inner <= n / 8
+
+
+def rtb_max_leaf():
+    return 4
