@@ -1290,7 +1290,22 @@ __device__ __forceinline__ Col cmul_col(Col c, Col d) { return Col{c.r * d.r, c.
 __device__ __forceinline__ Col cadd(Col c, Col d) { return Col{c.r + d.r, c.g + d.g, c.b + d.b}; }
 __device__ __forceinline__ Col cdiv(Col c, float v) { return Col{c.r / v, c.g / v, c.b / v}; }
 // Color::from_u8(0x87, 0xce, 0xeb), src/main.rs:303.
+// Color::gamma of the reference (powf(c, 1 / 2.2) per channel, src/objects.rs:151-156) as
+// exp2(log2(c) / 2.2) on the hardware's exp2 / log2 (about 1e-6 relative, far inside the 1-LSB
+// colour tolerance that libm differences already need): the full-precision powf was most of the
+// resolve kernel's instructions. 0 stays 0, negative stays NaN.
+#ifndef RT_FAST_GAMMA
+#define RT_FAST_GAMMA 1
+#endif
+__device__ __forceinline__ float gamma22_1(float c) {
+#if RT_FAST_GAMMA
+    return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 2.2f));
+#else
+    return powf(c, 1.0f / 2.2f);
+#endif
+}
 __device__ __forceinline__ Col sky() { return Col{135.0f / 255.0f, 206.0f / 255.0f, 235.0f / 255.0f}; }
+__device__ __forceinline__ Col gamma22(Col c) { return Col{gamma22_1(c.r), gamma22_1(c.g), gamma22_1(c.b)}; }
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     h ^= h >> 16;
@@ -1506,7 +1521,7 @@ __global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams 
         color = cadd(color, diffuse_color);
     }
     // Gamma only for samples that hit something; the sky is returned as is, src/main.rs:302-310.
-    if (hit_any) color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+    if (hit_any) color = gamma22(color);
     else color = inside ? sky() : Col{0.0f, 0.0f, 0.0f};
     if (hit_ids && inside) hit_ids[sample_index] = h.tri;
     if (STATS) flush_stats(st, stats);
@@ -1722,7 +1737,7 @@ __global__ __launch_bounds__(BLOCK) void k_wf_resolve(SceneView sv, DevRenderPar
         const rt_f3 sun_dir = g_normalize(sun - pos);
         if ((stt & RT_ST_LIT) && !(stt & RT_ST_OCC))
             color = cmul(tcol, g_dot(normal, sun_dir) * sv.objs[stt >> 8].albedo);
-        color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+        color = gamma22(color);
     } else {
         color = pm.inside ? sky() : Col{0.0f, 0.0f, 0.0f};
     }
@@ -1901,7 +1916,7 @@ __global__ __launch_bounds__(BLOCK) void k_wf_resolve_diffuse(SceneView sv, DevR
         diffuse_color = cdiv(diffuse_color, (float)p.diffuse_scatt);
         color = cadd(color, Col{0.0f, 0.0f, 0.0f});  // the mirror term of a surface that reflects nothing
         color = cadd(color, diffuse_color);
-        color = Col{powf(color.r, 1.0f / 2.2f), powf(color.g, 1.0f / 2.2f), powf(color.b, 1.0f / 2.2f)};
+        color = gamma22(color);
     } else {
         color = pm.inside ? sky() : Col{0.0f, 0.0f, 0.0f};
     }
