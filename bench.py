@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the trace_ray hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the synthetic
+Workload (the configuration the headline metric is quoted on): the synthetic
 1,000,000-triangle soup (PCG32 seed 0x5EED0001), one 3840x2160 frame at four samples per pixel:
 camera rays generated on the device, nearest-hit search, one sun shadow ray per lit hit, shading,
 sub-sample average, RGBA8. One step = one frame. Mrays/s counts nearest-hit plus shadow searches.

@@ -412,7 +412,7 @@ def test_device_built_tree_gives_the_same_answers(which, ctx, oracle, default_ob
 
 
 def test_full_size_properties_soup_1m(ctx, oracle):
-    """BASELINE configuration 3 at full size: 1,000,000 triangles, 3840x2160, four samples. The
+    """The benchmark workload at full size: 1,000,000 triangles, 3840x2160, four samples. The
     oracle cannot scan it in full in test time, so: a strided subsample is compared ray by ray, the
     frame is deterministic across runs, and the hit-id buffer is consistent with the frame."""
     objs = scenes.soup(1_000_000, 0x5EED0001)
