@@ -210,9 +210,9 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total * args.steps / elapsed / 1e6
         # Roofline of the dominant kernel, the camera-ray kernel (k_wf_primary), per launch.
-        # Algorithmic bytes = what one launch has to move to and from HBM: 28 B written per sample
-        # (hit point + id 16 B, state 4 B, sort key 4 B, sort value 4 B; camera rays are generated
-        # on the device, 0 B in) + the wide tree, the triangle records and the normals/colours read
+        # Algorithmic bytes = what one launch has to move to and from HBM: 24 B written per sample
+        # (hit point + id 16 B, state 4 B, sort key 4 B; camera rays are generated on the device,
+        # 0 B in) + the wide tree, the triangle records and the normals/colours read
         # once (they fit in L2 / Infinity Cache, so a launch needs them from HBM at most once).
         # "requested_bytes_per_launch" is what the kernel's loads ask the caches for (32 B per child
         # box a wave tests + 48 B per triangle record a wave fetches, from the kernel's own counters
@@ -221,8 +221,8 @@ def main():
         my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
         n_samples_rank = st["primary_rays"]
         sizes = scene.sizes()
-        alg_bytes = 28 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
-        requested_bytes = 28 * n_samples_rank + st["primary_fetch_bytes"]
+        alg_bytes = 24 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
+        requested_bytes = 24 * n_samples_rank + st["primary_fetch_bytes"]
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (collected with

@@ -115,11 +115,11 @@ struct FrameWork {
     float4* samp = nullptr;
     uint32_t* state = nullptr;
     uint32_t* keys[2] = {nullptr, nullptr};
-    uint32_t* vals[2] = {nullptr, nullptr};
+    uint32_t* order = nullptr;  // slot numbers in sorted key order
     void* temp = nullptr;
     size_t temp_bytes = 0;
     void release() {
-        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)vals[0], (void*)vals[1], temp})
+        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, temp})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }
@@ -204,10 +204,9 @@ int ensure_work(FrameWork& w, size_t n, hipStream_t stream) {
     HIP_TRY(rtk::sort_pairs_u32(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, n, 32, stream));
     HIP_TRY(hipMalloc((void**)&w.samp, n * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&w.state, n * 4));
-    for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMalloc((void**)&w.keys[k], n * 4));
-        HIP_TRY(hipMalloc((void**)&w.vals[k], n * 4));
-    }
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&w.keys[k], n * 4));
+    // The unsorted values are the slot numbers themselves and are never stored.
+    HIP_TRY(hipMalloc((void**)&w.order, n * 4));
     HIP_TRY(hipMalloc(&w.temp, std::max<size_t>(tb, 16)));
     w.temp_bytes = tb;
     w.capacity = n;
@@ -352,17 +351,17 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         dp.n_tiles = std::min(run_tiles, total_tiles - first);
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
         const LightProj lp = light_projection(s, p, n_slots);
-        HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], w.vals[0], d_stats, stream));
+        HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, stream));
         if (last_run) HIP_TRY(mark(1));
         if (primary_stats && d_stats && last_run) {
             HIP_TRY(hipStreamSynchronize(stream));
             HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
         }
         size_t tb = w.temp_bytes;
-        HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], w.vals[0], w.vals[1], n_slots, lp.key_bits, stream));
+        HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], nullptr, w.order, n_slots, lp.key_bits, stream));
         if (last_run) HIP_TRY(mark(2));
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
-                               w.vals[1], w.samp, w.state, d_stats, stream));
+                               w.order, w.samp, w.state, d_stats, stream));
         if (mode == 0) {
             if (last_run) HIP_TRY(mark(3));
             HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
@@ -373,12 +372,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             rc = take_counter(s->ctx, stream, &counter);
             if (rc != RT_OK) return rc;
             HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, d_list, (uint32_t)n_rays, counter, w.samp, w.state, bw.samp,
-                                   bw.state, bw.keys[0], bw.vals[0], d_stats, stream));
+                                   bw.state, bw.keys[0], d_stats, stream));
             size_t tb2 = bw.temp_bytes;
-            HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], bw.vals[0], bw.vals[1], n_rays,
+            HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], nullptr, bw.order, n_rays,
                                         lp2.key_bits, stream));
             HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_rays, lp2.key_bits > 16 ? lp2.key_bits - 16 : 0u,
-                                   bw.keys[1], bw.vals[1], bw.samp, bw.state, d_stats, stream));
+                                   bw.keys[1], bw.order, bw.samp, bw.state, d_stats, stream));
             if (last_run) HIP_TRY(mark(3));
             HIP_TRY(rtk::wf_resolve_diffuse(s->view, dp, d_list, w.samp, w.state, bw.samp, bw.state, d_rgba8, d_hit_ids,
                                             stream));

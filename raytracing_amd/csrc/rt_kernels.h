@@ -26,7 +26,7 @@ hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t*
                   uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats, hipStream_t s);
 // Camera + shadow frame as separate kernels around a sort (see rt_kernels.hip).
 hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                      float4* d_samp, uint32_t* d_state, uint32_t* d_keys, uint32_t* d_vals, DevStats* d_stats,
+                      float4* d_samp, uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats,
                       hipStream_t s);
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
@@ -37,7 +37,7 @@ hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint3
 // then shading of both levels. n_rays = sample slots of the launch * p.diffuse_scatt.
 hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
                      uint32_t n_rays, uint32_t* d_counter, const float4* d_samp, const uint32_t* d_state,
-                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats,
+                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, DevStats* d_stats,
                      hipStream_t s);
 hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list,
                               const float4* d_samp, const uint32_t* d_state, const float4* d_dsamp,

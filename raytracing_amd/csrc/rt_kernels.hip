@@ -1661,8 +1661,7 @@ template <bool STATS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv, DevRenderParams p, LightProj lp,
                                                       const uint32_t* __restrict__ tile_list,
                                                       float4* __restrict__ samp, uint32_t* __restrict__ state,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                      DevStats* __restrict__ stats) {
+                                                      uint32_t* __restrict__ keys, DevStats* __restrict__ stats) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
     const PixelMap<BLOCK> pm(p, tile_list, true);
@@ -1683,7 +1682,6 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     // Light-space key: the hit point projected from the sun onto the plane across the light's
     // dominant axis; points on one line to the sun get (nearly) one key.
     keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
-    vals[slot] = slot;
     if (STATS) flush_stats(st, stats);
 }
 
@@ -1814,12 +1812,10 @@ struct BounceSource {
     float4* dsamp;
     uint32_t* dstate;
     uint32_t* dkeys;
-    uint32_t* dvals;
     __device__ __forceinline__ void store(uint32_t j, float4 out, uint32_t out_state, uint32_t key) const {
         dsamp[j] = out;
         dstate[j] = out_state;
         dkeys[j] = key;
-        dvals[j] = j;
     }
     __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
         const uint32_t slot = j / p.diffuse_scatt, k = j % p.diffuse_scatt;
@@ -1856,10 +1852,10 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
                                                     uint32_t* __restrict__ counter, const float4* __restrict__ samp,
                                                     const uint32_t* __restrict__ state, float4* __restrict__ dsamp,
                                                     uint32_t* __restrict__ dstate, uint32_t* __restrict__ dkeys,
-                                                    uint32_t* __restrict__ dvals, DevStats* __restrict__ stats) {
+                                                    DevStats* __restrict__ stats) {
     __shared__ uint2 s_stack[RT_WALK_LDS * 64];
     LaneStats st;
-    const BounceSource src{sv, p, lp, tile_list, samp, state, dsamp, dstate, dkeys, dvals};
+    const BounceSource src{sv, p, lp, tile_list, samp, state, dsamp, dstate, dkeys};
     persistent_walk<false, STATS>(sv, n_rays, counter, src, s_stack, st);
     if (STATS) flush_stats(st, stats);
 }
@@ -2058,17 +2054,17 @@ hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t*
 }
 
 hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                      float4* d_samp, uint32_t* d_state, uint32_t* d_keys, uint32_t* d_vals, DevStats* d_stats,
+                      float4* d_samp, uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats,
                       hipStream_t s) {
     const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_WF_BLOCK / p.spp));
     if (blocks == 0) return hipSuccess;
     const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
         hipLaunchKernelGGL((k_wf_primary<true, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
-                           d_samp, d_state, d_keys, d_vals, d_stats);
+                           d_samp, d_state, d_keys, d_stats);
     else
         hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
-                           d_samp, d_state, d_keys, d_vals, d_stats);
+                           d_samp, d_state, d_keys, d_stats);
     return hipGetLastError();
 }
 
@@ -2097,15 +2093,15 @@ hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint3
 
 hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
                      uint32_t n_rays, uint32_t* d_counter, const float4* d_samp, const uint32_t* d_state,
-                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, uint32_t* d_dvals, DevStats* d_stats,
+                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, DevStats* d_stats,
                      hipStream_t s) {
     if (n_rays == 0) return hipSuccess;
     if (d_stats)
         hipLaunchKernelGGL((k_wf_bounce<true>), dim3(persistent_grid(n_rays)), dim3(64), 0, s, sv, p, lp, d_tile_list,
-                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
+                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_stats);
     else
         hipLaunchKernelGGL((k_wf_bounce<false>), dim3(persistent_grid(n_rays)), dim3(64), 0, s, sv, p, lp, d_tile_list,
-                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_dvals, d_stats);
+                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_stats);
     return hipGetLastError();
 }
 
