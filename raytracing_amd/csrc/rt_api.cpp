@@ -115,11 +115,12 @@ struct FrameWork {
     float4* samp = nullptr;
     uint32_t* state = nullptr;
     uint32_t* keys[2] = {nullptr, nullptr};
-    uint32_t* order = nullptr;  // slot numbers in sorted key order
+    uint32_t* order = nullptr;  // slot numbers in sorted key order (before the sort: ray queues of the levels)
+    uint32_t* counts = nullptr; // rays queued per level of the secondary-ray tree
     void* temp = nullptr;
     size_t temp_bytes = 0;
     void release() {
-        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, temp})
+        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, temp})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }
@@ -207,6 +208,7 @@ int ensure_work(FrameWork& w, size_t n, hipStream_t stream) {
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&w.keys[k], n * 4));
     // The unsorted values are the slot numbers themselves and are never stored.
     HIP_TRY(hipMalloc((void**)&w.order, n * 4));
+    HIP_TRY(hipMalloc((void**)&w.counts, (RT_MAX_REFLECT + 1) * 4));
     HIP_TRY(hipMalloc(&w.temp, std::max<size_t>(tb, 16)));
     w.temp_bytes = tb;
     w.capacity = n;
@@ -304,8 +306,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     bool reflective = false;
     for (const DevObject& ob : s->objects) reflective = reflective || ob.reflectivity > 0.0f;
     const int mode = p->diffuse_depth > 1 ? 2 : ((reflective && p->reflect_depth > 1) ? 1 : 0);
-    // One-kernel frame: mirror bounces, diffuse bounces over scenes with mirrors, or on request.
-    const bool pipeline = (mode == 0 || (mode == 2 && !reflective)) && !std::getenv("RAYS_HIP_MEGAKERNEL");
+    // One-kernel frame: mirror bounces without diffuse scattering (few rays, all from the sample's
+    // own lane), or on request.
+    const bool pipeline = mode != 1 && !std::getenv("RAYS_HIP_MEGAKERNEL");
     if (!pipeline) {
         HIP_TRY(mark(0));
         HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
@@ -317,28 +320,35 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         return RT_OK;
     }
     // Pipeline of small kernels. Camera + shadow rays only (mode 0): camera-ray kernel, light-space
-    // sort of the shadow rays, shadow kernel, resolve kernel, over the whole frame at once. With one
-    // diffuse bounce (mode 2): the same, then the scatter rays, their sorted shadow rays, and the
-    // resolve of both levels, over runs of tiles sized so that a run's scatter rays fit the
-    // workspace.
+    // sort of the shadow rays, shadow kernel, resolve kernel, over the whole frame at once. With
+    // diffuse scattering (mode 2): the same, then the tree of secondary rays level by level, the
+    // sorted shadow rays of all levels, and the resolve of everything, over runs of tiles sized so
+    // that a run's secondary rays fit the workspace.
     const uint32_t tile_slots = RT_TILE * RT_TILE * spp;
     if ((size_t)dp.n_tiles * tile_slots >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "frame has too many samples");
     if (dp.n_tiles == 0) return RT_OK;
     uint32_t run_tiles = dp.n_tiles;
+    RayTree tr{};
     if (mode == 2) {
-        // Scatter rays per run of tiles (64 Mi: 2.3 GB of workspace); RAYS_HIP_BOUNCE_RAYS overrides.
+        // Scatter rays off every hit; off a mirror one mirror ray more, and every branch is followed
+        // from mirror to mirror down to reflect_depth (the camera ray is depth 1, level 0 is depth 2).
+        tr.scatt = p->diffuse_scatt;
+        tr.mirror = (reflective && p->reflect_depth > 1) ? 1u : 0u;
+        tr.branches = tr.scatt + tr.mirror;
+        tr.levels = tr.mirror ? p->reflect_depth - 1 : 1u;
+        // Secondary-ray records per run of tiles (64 Mi: 2.3 GB of workspace); RAYS_HIP_BOUNCE_RAYS overrides.
         const char* e = std::getenv("RAYS_HIP_BOUNCE_RAYS");
         const long long v = e ? std::atoll(e) : 0;
         const size_t cap = v > 0 ? (size_t)v : ((size_t)64 << 20);
-        const size_t per_tile = (size_t)tile_slots * p->diffuse_scatt;
-        if (per_tile >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many scatter rays per tile");
+        const size_t per_tile = (size_t)tile_slots * tr.branches * tr.levels;
+        if (per_tile >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays per tile");
         run_tiles = (uint32_t)std::min<size_t>(dp.n_tiles, std::max<size_t>(1, cap / per_tile));
     }
     const size_t run_slots = (size_t)run_tiles * tile_slots;
     rc = ensure_work(s->work, run_slots, stream);
     if (rc != RT_OK) return rc;
     if (mode == 2) {
-        rc = ensure_work(s->bounce_work, run_slots * p->diffuse_scatt, stream);
+        rc = ensure_work(s->bounce_work, run_slots * tr.branches * tr.levels, stream);
         if (rc != RT_OK) return rc;
     }
     FrameWork& w = s->work;
@@ -366,21 +376,32 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             if (last_run) HIP_TRY(mark(3));
             HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
         } else {
-            const size_t n_rays = n_slots * p->diffuse_scatt;
+            tr.level_rays = (uint32_t)(n_slots * tr.branches);
+            const size_t n_rays = (size_t)tr.level_rays * tr.levels;
             const LightProj lp2 = light_projection(s, p, n_rays);
-            uint32_t* counter = nullptr;
-            rc = take_counter(s->ctx, stream, &counter);
-            if (rc != RT_OK) return rc;
-            HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, d_list, (uint32_t)n_rays, counter, w.samp, w.state, bw.samp,
-                                   bw.state, bw.keys[0], d_stats, stream));
+            // Deeper levels only hold the rays that bounced off a mirror; the rest of their records
+            // says "no ray" from the start. The lists of those rays use the sort's output array.
+            HIP_TRY(hipMemsetAsync(bw.counts, 0, (RT_MAX_REFLECT + 1) * 4, stream));
+            if (tr.levels > 1) {
+                const size_t deeper = n_rays - tr.level_rays;
+                HIP_TRY(hipMemsetAsync(bw.state + tr.level_rays, 0, deeper * 4, stream));
+                HIP_TRY(hipMemsetAsync(bw.keys[0] + tr.level_rays, 0xFF, deeper * 4, stream));
+            }
+            for (uint32_t level = 0; level < tr.levels; ++level) {
+                uint32_t* counter = nullptr;
+                rc = take_counter(s->ctx, stream, &counter);
+                if (rc != RT_OK) return rc;
+                HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, tr, level, d_list, counter, w.samp, w.state, bw.samp, bw.state,
+                                       bw.keys[0], bw.order, bw.counts, d_stats, stream));
+            }
             size_t tb2 = bw.temp_bytes;
             HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], nullptr, bw.order, n_rays,
                                         lp2.key_bits, stream));
             HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_rays, lp2.key_bits > 16 ? lp2.key_bits - 16 : 0u,
                                    bw.keys[1], bw.order, bw.samp, bw.state, d_stats, stream));
             if (last_run) HIP_TRY(mark(3));
-            HIP_TRY(rtk::wf_resolve_diffuse(s->view, dp, d_list, w.samp, w.state, bw.samp, bw.state, d_rgba8, d_hit_ids,
-                                            stream));
+            HIP_TRY(rtk::wf_resolve_tree(s->view, dp, tr, d_list, w.samp, w.state, bw.samp, bw.state, d_rgba8,
+                                         d_hit_ids, stream));
         }
     }
     HIP_TRY(mark(4));

@@ -72,6 +72,14 @@ struct LightProj {
     uint32_t key_bits;             // leading bits of the 32-bit interleaved key that are kept (even, 8..32)
 };
 
+// Secondary rays of a sample in the kernel pipeline. `branches` rays leave the camera ray's hit:
+// `scatt` scatter rays, then one mirror ray if `mirror`. Each branch is followed through up to
+// `levels` hits, from one to the next by a mirror bounce. The record of ray j (= sample slot *
+// branches + branch) at level l sits at l * level_rays + j.
+struct RayTree {
+    uint32_t branches, scatt, mirror, levels, level_rays;
+};
+
 struct DevStats {
     unsigned long long rays, box_tests, tri_tests, node_visits, fetch_bytes;
     unsigned long long walks[4];  // beam walks, mask walks, beam refits, mask-walk node fetches (per wave)

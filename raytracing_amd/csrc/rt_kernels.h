@@ -33,15 +33,19 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
                      DevStats* d_stats, hipStream_t s);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
-// One diffuse bounce as a pipeline (scenes without mirrors): scatter rays of the launch's samples,
-// then shading of both levels. n_rays = sample slots of the launch * p.diffuse_scatt.
-hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                     uint32_t n_rays, uint32_t* d_counter, const float4* d_samp, const uint32_t* d_state,
-                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, DevStats* d_stats,
-                     hipStream_t s);
-hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list,
-                              const float4* d_samp, const uint32_t* d_state, const float4* d_dsamp,
-                              const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
+// Diffuse and mirror bounces as a pipeline: one launch of wf_bounce per level of the tree of
+// secondary rays (level 0 reads the camera rays' records, level l the records of level l - 1), then
+// the shading of all levels. The record arrays and d_queues hold tr.levels * tr.level_rays entries,
+// d_counts one word per level. Before level 0 the caller zeroes d_counts and presets the records of
+// the deeper levels to "no ray": d_dstate 0, d_dkeys all ones.
+hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const RayTree& tr,
+                     uint32_t level, const uint32_t* d_tile_list, uint32_t* d_counter, const float4* d_samp,
+                     const uint32_t* d_state, float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys,
+                     uint32_t* d_queues, uint32_t* d_counts, DevStats* d_stats, hipStream_t s);
+hipError_t wf_resolve_tree(const SceneView& sv, const DevRenderParams& p, const RayTree& tr,
+                           const uint32_t* d_tile_list, const float4* d_samp, const uint32_t* d_state,
+                           const float4* d_dsamp, const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids,
+                           hipStream_t s);
 // Stable radix sort of (u32 key, u32 value) pairs on the low key_bits bits of the key. With
 // temp == nullptr only *temp_bytes is set.
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,

@@ -923,11 +923,19 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // waits for the last one leaves most lanes idle most of the time.
 // The walk of closest_all is kept as a per-lane state machine: `walking` lanes take one node or one
 // leaf per turn; the others move to the next object whose box their ray meets (after the trailing
-// triangles of the one they leave), or deliver their result and become idle. Ray indices are taken
-// from a global counter, RT_REFILL or more at a time; the loop ends when the counter has passed the
-// last ray and no lane holds one.
+// triangles of the one they leave), or deliver their result and become idle. A wave takes ray
+// indices RT_CHUNK at a time and hands them to its idle lanes RT_REFILL or more at a time. Most
+// chunks are the wave's own by number (wave w owns chunks w, w + waves, ...), the last
+// 2^-RT_DYNAMIC_SHIFT of the rays are handed out through a global counter so that the waves end
+// together: an atomic on one address shared by the whole device takes about 12 ns, which would
+// bound a launch of cheap rays if every chunk went through it. The loop ends when the wave has had
+// its own chunks, the counter has passed the last ray and no lane holds one. Every wave overshoots
+// the counter by at most one chunk, so n_rays must stay RT_WALK_HEADROOM below 2^32.
 // Source: bool init(j, o, d) gives ray j (false: there is none, and the source has stored whatever
-// stands for it), void emit(j, hit, o, d) stores its result. In shadow mode (ANY) the walk ends at
+// stands for it), void emit(j, hit, o, d) stores its result. A source with QUEUES set collects
+// follow-up rays while it emits (per wave, in LDS) and is given the chance to write them out with
+// the whole wave: flush(lane, false) after every turn in which a lane emitted, flush(lane, true) at
+// the end. In shadow mode (ANY) the walk ends at
 // the first occluder and hit.tri != RT_MISS says "occluded".
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_WALK_LDS
@@ -939,6 +947,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #ifndef RT_WALK_WAVES
 #define RT_WALK_WAVES 8
 #endif
+#ifndef RT_CHUNK
+#define RT_CHUNK 64
+#endif
+#ifndef RT_DYNAMIC_SHIFT
+#define RT_DYNAMIC_SHIFT 2
+#endif
+#define RT_WALK_MAX_GRID 8192u                              // waves of a persistent launch
+#define RT_WALK_HEADROOM (RT_WALK_MAX_GRID * RT_CHUNK + 64u)  // counter overshoot at the end of a launch
 using WalkStack = LaneStackT<RT_WALK_LDS, 64>;
 
 template <bool ANY, bool STATS, class Source>
@@ -950,6 +966,10 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
     stk.sp = 0;
     bool has = false, walking = false, in_obj = false;
     bool exhausted = false;  // wave-uniform: the counter has passed the last ray
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: ray indices taken and not yet handed out
+    // Whole rounds of one chunk per wave inside the first (1 - 2^-RT_DYNAMIC_SHIFT) of the rays.
+    const uint32_t static_turns = (n_rays - (n_rays >> RT_DYNAMIC_SHIFT)) / (gridDim.x * (uint32_t)RT_CHUNK);
+    uint32_t turn = 0;
     uint32_t j = 0, oi = 0, cur = 0, local_best = 0;
     rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 1.0f), inv = d;
     float nox = 0.0f, noy = 0.0f, noz = 0.0f, closest = RT_INF;
@@ -961,14 +981,30 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
         if (!exhausted && n_idle >= RT_REFILL) {
-            const int first = __builtin_ctzll(idle);
-            uint32_t base = 0;
-            if ((int)lane == first) base = atomicAdd(counter, n_idle);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-            exhausted = base + n_idle >= n_rays || base + n_idle < base;
-            const uint32_t idx = base + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-            if (!has && idx < n_rays && idx >= base) {
-                j = idx;
+            if (chunk_next == chunk_end) {
+                // The wave's own chunks first (chunk numbers blockIdx.x, + gridDim.x, ...: no
+                // traffic), then chunks of the shared remainder, which evens out the end.
+                uint32_t base;
+                if (turn < static_turns) {
+                    base = (turn * gridDim.x + blockIdx.x) * (uint32_t)RT_CHUNK;
+                    ++turn;
+                } else {
+                    const int first = __builtin_ctzll(idle);
+                    uint32_t got = 0;
+                    if ((int)lane == first) got = atomicAdd(counter, (uint32_t)RT_CHUNK);
+                    base = static_turns * gridDim.x * (uint32_t)RT_CHUNK +
+                           (uint32_t)__builtin_amdgcn_readlane((int)got, first);
+                }
+                exhausted = base >= n_rays;
+                chunk_next = exhausted ? 0u : base;
+                chunk_end = exhausted ? 0u : (n_rays - base < (uint32_t)RT_CHUNK ? n_rays : base + (uint32_t)RT_CHUNK);
+            }
+            const uint32_t left = chunk_end - chunk_next, take = n_idle < left ? n_idle : left;
+            const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+            const uint32_t first_idx = chunk_next;
+            chunk_next += take;
+            if (!has && rank < take) {
+                j = first_idx + rank;
                 if (src.init(j, o, d)) {
                     has = true;
                     walking = false;
@@ -990,6 +1026,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             if (exhausted) break;
             continue;
         }
+        bool emitted = false;
         if (has && !walking) {
             // Leave the current object (its trailing n % 8 triangles, src/main.rs:157-169: scalar
             // arithmetic, `closest` is not lowered, the last qualifying one wins), then find the
@@ -1038,7 +1075,11 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                 hit.closest = closest;
                 src.emit(j, hit, o, d);
                 has = false;
+                emitted = true;
             }
+        }
+        if constexpr (Source::QUEUES) {
+            if (__ballot(emitted) != 0ull) src.flush(lane, false);
         }
         if (has && walking) {
             bool need_pop = true;
@@ -1071,10 +1112,12 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             }
         }
     }
+    if constexpr (Source::QUEUES) src.flush(lane, true);
 }
 
 // Rays of a batch call.
 struct BatchSource {
+    static constexpr bool QUEUES = false;
     const rt_ray* rays;
     rt_hit* out;
     __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
@@ -1094,6 +1137,7 @@ struct BatchSource {
 };
 
 struct BatchAnySource {
+    static constexpr bool QUEUES = false;
     const rt_ray* rays;
     uint8_t* out;
     __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
@@ -1764,17 +1808,19 @@ __global__ __launch_bounds__(BLOCK) void k_wf_resolve(SceneView sv, DevRenderPar
 // its slot inside the shard's slab is its rank among that shard's tiles in ascending tile id,
 // given by tile_slot[t].
 // ---------------------------------------------------------------------------------------------
-// Frames with one diffuse bounce (DIFFUSE_DEPTH = 2) over scenes without mirrors, as a pipeline:
+// Frames with diffuse scattering at the camera ray's hit (DIFFUSE_DEPTH = 2), as a pipeline:
 //   k_wf_primary, sort, k_wf_shadow       camera rays and their shadow rays, as above
-//   k_wf_bounce                           the scatter rays of every hit sample: nearest hit by the
-//                                         per-lane walk (they share an origin, not a direction); per
-//                                         ray: hit point, id, state, light-space key
-//   sort, k_wf_shadow                     the scatter rays' shadow rays, in light-space order
-//   k_wf_resolve_diffuse                  shading of both levels, gamma, average, RGBA8
-// Scatter ray j of a launch belongs to sample slot j / scatt, direction j % scatt. Small kernels
-// instead of one: the per-lane walk needs occupancy more than anything (8 waves per SIMD here, 3 in
-// the one-kernel frame), and half of the bounce level's rays are shadow rays that the sorted beam
-// walk handles an order of magnitude faster.
+//   k_wf_bounce, once per level           level 0: the scatter rays of every hit sample and, off a
+//                                         mirror, the mirror ray; level l: the mirror bounces off the
+//                                         hits of level l - 1. Nearest hit by the per-lane walk (the
+//                                         rays share origins, not directions); per ray: hit point,
+//                                         id, state, light-space key
+//   sort, k_wf_shadow                     the shadow rays of all levels, in light-space order
+//   k_wf_resolve_tree                     shading of every level, gamma, average, RGBA8
+// Small kernels instead of one: the per-lane walk needs occupancy more than anything (8 waves per
+// SIMD here, 3 in the one-kernel frame), lanes whose sample has no ray at some level are refilled
+// instead of idling, and half of all rays are shadow rays that the sorted beam walk handles an
+// order of magnitude faster.
 // ---------------------------------------------------------------------------------------------
 // Pixel and sample of a launch-relative sample slot (the inverse of PixelMap's slot numbering).
 struct SlotMap {
@@ -1801,74 +1847,181 @@ struct SlotMap {
     }
 };
 
-// Scatter ray j of a launch: origin and normal from its sample's stored hit, direction k = j % scatt.
-struct BounceSource {
+// Mirror direction of src/main.rs:245.
+__device__ __forceinline__ rt_f3 reflect_dir(rt_f3 d, rt_f3 n) { return d - 2.0f * n * g_dot(d, n); }
+
+// Ray j of level `level` of the secondary-ray tree: branch j % branches of sample slot j / branches.
+// Level 0 leaves the camera ray's hit (scatter direction k for branch k < scatt, the mirror direction
+// for the branch after them) and runs over every j; level l > 0 is the mirror bounce off that
+// branch's hit at level l - 1 and runs over the queue of rays the level before filled: those that
+// hit a mirror. Directions are not stored: they follow from the stored triangle ids along the branch.
+// Records of rays that do not exist: level 0 stores "no hit, no shadow ray" itself, the deeper
+// levels are preset to that before the first launch.
+#define RT_QUEUE_LDS 128  // follow-up rays a wave collects before writing them out (>= 2 * 64 - 1)
+struct TreeSource {
+    static constexpr bool QUEUES = true;
     const SceneView& sv;
     const DevRenderParams& p;
     const LightProj& lp;
+    const RayTree& tr;
+    uint32_t level;
     const uint32_t* tile_list;
     const float4* samp;
     const uint32_t* state;
     float4* dsamp;
     uint32_t* dstate;
     uint32_t* dkeys;
-    __device__ __forceinline__ void store(uint32_t j, float4 out, uint32_t out_state, uint32_t key) const {
-        dsamp[j] = out;
-        dstate[j] = out_state;
-        dkeys[j] = key;
+    const uint32_t* queue;  // this level's rays (level > 0)
+    uint32_t* next_queue;   // the next level's rays and their count, null at the last level
+    uint32_t* next_count;
+    uint32_t* s_q;          // LDS, per wave: RT_QUEUE_LDS entries, then their count
+    __device__ __forceinline__ bool none(uint32_t j) const {
+        dstate[j] = 0u;
+        dkeys[j] = 0xFFFFFFFFu;
+        return false;
     }
-    __device__ __forceinline__ bool init(uint32_t j, rt_f3& o, rt_f3& d) const {
-        const uint32_t slot = j / p.diffuse_scatt, k = j % p.diffuse_scatt;
-        if (!(state[slot] & RT_ST_HIT)) {
-            store(j, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS)), 0u, 0xFFFFFFFFu);
-            return false;
+    __device__ __forceinline__ bool init(uint32_t idx, rt_f3& o, rt_f3& d) const {
+        const uint32_t j = level ? queue[idx] : idx;
+        const uint32_t slot = j / tr.branches, k = j % tr.branches;
+        const uint32_t ps = state[slot];
+        if (level == 0) {
+            if (!(ps & RT_ST_HIT)) return none(j);
+            if (k >= tr.scatt && !(sv.objs[ps >> 8].reflectivity > 0.0f)) return none(j);
         }
         const SlotMap sm(p, tile_list, slot);
         const float4 a = samp[slot];
         const rt_f3 normal = ld3(sv.tri_data + 6 * (size_t)__float_as_uint(a.w));
-        rt_f3 tang1, tang2;
-        tangent_vectors(normal, &tang1, &tang2);
         o = f3(a.x, a.y, a.z);
-        d = diffuse_dir(p.seed, sm.sample_index, k, normal, tang1, tang2);
+        if (k < tr.scatt) {
+            rt_f3 tang1, tang2;
+            tangent_vectors(normal, &tang1, &tang2);
+            d = diffuse_dir(p.seed, sm.sample_index, k, normal, tang1, tang2);
+        } else {
+            d = reflect_dir(camera_dir(p, sm.x, sm.y, sm.s), normal);
+        }
+        for (uint32_t l = 0; l < level; ++l) {
+            const float4 r = dsamp[(size_t)l * tr.level_rays + j];
+            d = reflect_dir(d, ld3(sv.tri_data + 6 * (size_t)__float_as_uint(r.w)));
+            o = f3(r.x, r.y, r.z);
+        }
         return true;
     }
-    __device__ __forceinline__ void emit(uint32_t j, const HitD& h, rt_f3 o, rt_f3 d) const {
+    __device__ __forceinline__ void emit(uint32_t idx, const HitD& h, rt_f3 o, rt_f3 d) const {
+        const uint32_t j = level ? queue[idx] : idx;
+        const size_t i = (size_t)level * tr.level_rays + j;
+        bool spawn = false;
         if (h.tri == RT_MISS) {
-            store(j, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS)), 0u, 0xFFFFFFFFu);
-            return;
+            dstate[i] = 0u;
+            dkeys[i] = 0xFFFFFFFFu;
+        } else {
+            const Surface s2 = surface_of(sv, h, o, d);
+            const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+            const rt_f3 sun_dir = g_normalize(sun - s2.pos);
+            const bool lit = g_dot(s2.normal, sun_dir) > 0.0f;
+            dsamp[i] = make_float4(s2.pos.x, s2.pos.y, s2.pos.z, __uint_as_float(h.tri));
+            dstate[i] = RT_ST_HIT | (lit ? RT_ST_LIT : 0u) | (h.obj << 8);
+            dkeys[i] = lit ? light_key(lp, s2.pos) : 0xFFFFFFFFu;
+            spawn = next_queue != nullptr && s2.reflectivity > 0.0f;
         }
-        const Surface s2 = surface_of(sv, h, o, d);
-        const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-        const rt_f3 sun_dir = g_normalize(sun - s2.pos);
-        const bool lit = g_dot(s2.normal, sun_dir) > 0.0f;
-        store(j, make_float4(s2.pos.x, s2.pos.y, s2.pos.z, __uint_as_float(h.tri)),
-              RT_ST_HIT | (lit ? RT_ST_LIT : 0u) | (h.obj << 8), lit ? light_key(lp, s2.pos) : 0xFFFFFFFFu);
+        // The lanes that emit in this turn and bounce on append to the wave's list together.
+        const unsigned long long mask = __ballot(spawn);
+        if (spawn) {
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t base = s_q[RT_QUEUE_LDS];
+            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            s_q[base + rank] = j;
+            if (rank == 0) s_q[RT_QUEUE_LDS] = base + (uint32_t)__builtin_popcountll(mask);
+        }
+    }
+    // Whole wave: writes the collected rays out once there are 64 (or any, at the end), one atomic
+    // per write. A turn adds at most 64, so the list never passes 127.
+    __device__ __forceinline__ void flush(uint32_t lane, bool all) const {
+        if (!next_queue) return;
+        const uint32_t n = s_q[RT_QUEUE_LDS];
+        if (n == 0 || (!all && n < 64u)) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_count, n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < n; i += 64u) next_queue[base + i] = s_q[i];
+        if (lane == 0) s_q[RT_QUEUE_LDS] = 0u;
     }
 };
 
+// counts: one word per level, the number of rays in that level's queue (level 0 has none: it runs
+// over all level_rays). queues: level l's list at l * level_rays.
 template <bool STATS>
-__global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp,
-                                                    const uint32_t* __restrict__ tile_list, uint32_t n_rays,
+__global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, DevRenderParams p, LightProj lp, RayTree tr,
+                                                    uint32_t level, const uint32_t* __restrict__ tile_list,
                                                     uint32_t* __restrict__ counter, const float4* __restrict__ samp,
-                                                    const uint32_t* __restrict__ state, float4* __restrict__ dsamp,
-                                                    uint32_t* __restrict__ dstate, uint32_t* __restrict__ dkeys,
+                                                    const uint32_t* __restrict__ state, float4* dsamp,
+                                                    uint32_t* dstate, uint32_t* __restrict__ dkeys,
+                                                    uint32_t* queues, uint32_t* counts,
                                                     DevStats* __restrict__ stats) {
     __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
+    if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
     LaneStats st;
-    const BounceSource src{sv, p, lp, tile_list, samp, state, dsamp, dstate, dkeys};
-    persistent_walk<false, STATS>(sv, n_rays, counter, src, s_stack, st);
+    const bool last = level + 1 >= tr.levels;
+    const uint32_t n = level ? counts[level] : tr.level_rays;
+    const TreeSource src{sv, p, lp, tr, level, tile_list, samp, state, dsamp, dstate, dkeys,
+                         queues + (size_t)level * tr.level_rays,
+                         last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
+                         last ? nullptr : counts + level + 1, s_q};
+    persistent_walk<false, STATS>(sv, n, counter, src, s_stack, st);
     if (STATS) flush_stats(st, stats);
 }
 
+// Sun light at a stored hit, src/main.rs:176-241, from its record.
+__device__ __forceinline__ Col record_light(const SceneView& sv, rt_f3 sun, float4 rec, uint32_t stt) {
+    if (!(stt & RT_ST_LIT) || (stt & RT_ST_OCC)) return Col{0.0f, 0.0f, 0.0f};
+    const float* td = sv.tri_data + 6 * (size_t)__float_as_uint(rec.w);
+    const rt_f3 sun_dir = g_normalize(sun - f3(rec.x, rec.y, rec.z));
+    return cmul(Col{td[3], td[4], td[5]}, g_dot(ld3(td), sun_dir) * sv.objs[stt >> 8].albedo);
+}
+
+// Colour a branch of the secondary-ray tree returns to the camera ray's hit: mirror_chain on the
+// stored records, folded back in the reference's order (color = direct + col * reflectivity).
+__device__ __forceinline__ Col branch_color(const SceneView& sv, const DevRenderParams& p, const RayTree& tr, rt_f3 sun,
+                                            const float4* __restrict__ dsamp, const uint32_t* __restrict__ dstate,
+                                            size_t j) {
+    Col direct[RT_MAX_REFLECT];
+    float refl[RT_MAX_REFLECT];
+    uint32_t n = 0;
+    Col tail;
+    for (uint32_t l = 0;; ++l) {
+        const size_t i = (size_t)l * tr.level_rays + j;
+        const uint32_t st2 = dstate[i];
+        if (!(st2 & RT_ST_HIT)) {
+            tail = sky();
+            break;
+        }
+        const Col c = record_light(sv, sun, dsamp[i], st2);
+        const float r = sv.objs[st2 >> 8].reflectivity;
+        if (l + 1 < tr.levels && r > 0.0f) {  // depth l + 2 < reflect_depth: the bounce was traced
+            direct[n] = c;
+            refl[n] = r;
+            ++n;
+            continue;
+        }
+        tail = c;
+        break;
+    }
+    while (n > 0) {
+        --n;
+        tail = cadd(direct[n], cmul(tail, refl[n]));
+    }
+    return tail;
+}
+
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_wf_resolve_diffuse(SceneView sv, DevRenderParams p,
-                                                              const uint32_t* __restrict__ tile_list,
-                                                              const float4* __restrict__ samp,
-                                                              const uint32_t* __restrict__ state,
-                                                              const float4* __restrict__ dsamp,
-                                                              const uint32_t* __restrict__ dstate,
-                                                              uint8_t* __restrict__ rgba8,
-                                                              uint32_t* __restrict__ hit_ids) {
+__global__ __launch_bounds__(BLOCK) void k_wf_resolve_tree(SceneView sv, DevRenderParams p, RayTree tr,
+                                                           const uint32_t* __restrict__ tile_list,
+                                                           const float4* __restrict__ samp,
+                                                           const uint32_t* __restrict__ state,
+                                                           const float4* __restrict__ dsamp,
+                                                           const uint32_t* __restrict__ dstate,
+                                                           uint8_t* __restrict__ rgba8,
+                                                           uint32_t* __restrict__ hit_ids) {
     __shared__ float s_col[3 * BLOCK];
     const PixelMap<BLOCK> pm(p, tile_list);
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
@@ -1883,34 +2036,25 @@ __global__ __launch_bounds__(BLOCK) void k_wf_resolve_diffuse(SceneView sv, DevR
         const float* td = sv.tri_data + 6 * (size_t)tri;
         const rt_f3 normal = ld3(td);
         const Col tcol = Col{td[3], td[4], td[5]};
-        const rt_f3 pos = f3(a.x, a.y, a.z);
         const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-        const rt_f3 sun_dir = g_normalize(sun - pos);
         const DevObject& ob = sv.objs[stt >> 8];
-        if ((stt & RT_ST_LIT) && !(stt & RT_ST_OCC)) color = cmul(tcol, g_dot(normal, sun_dir) * ob.albedo);
+        color = record_light(sv, sun, a, stt);
+        const size_t j0 = (size_t)slot * tr.branches;
+        Col reflect_color{0.0f, 0.0f, 0.0f};
+        if (tr.mirror && ob.reflectivity > 0.0f)
+            reflect_color = cmul(branch_color(sv, p, tr, sun, dsamp, dstate, j0 + tr.scatt), ob.reflectivity);
         const uint64_t sample_index = ((uint64_t)pm.y * p.width + pm.x) * spp + pm.s;
         rt_f3 tang1, tang2;
         tangent_vectors(normal, &tang1, &tang2);
         Col diffuse_color{0.0f, 0.0f, 0.0f};
-        for (uint32_t k = 0; k < p.diffuse_scatt; ++k) {
+        for (uint32_t k = 0; k < tr.scatt; ++k) {
             const rt_f3 vel = diffuse_dir(p.seed, sample_index, k, normal, tang1, tang2);
             const float light_power = g_dot(normal, vel);
-            const size_t j = (size_t)slot * p.diffuse_scatt + k;
-            const uint32_t st2 = dstate[j];
-            Col col = sky();
-            if (st2 & RT_ST_HIT) {
-                col = Col{0.0f, 0.0f, 0.0f};
-                if ((st2 & RT_ST_LIT) && !(st2 & RT_ST_OCC)) {
-                    const float4 b = dsamp[j];
-                    const float* td2 = sv.tri_data + 6 * (size_t)__float_as_uint(b.w);
-                    const rt_f3 sun_dir2 = g_normalize(sun - f3(b.x, b.y, b.z));
-                    col = cmul(Col{td2[3], td2[4], td2[5]}, g_dot(ld3(td2), sun_dir2) * sv.objs[st2 >> 8].albedo);
-                }
-            }
+            const Col col = branch_color(sv, p, tr, sun, dsamp, dstate, j0 + k);
             diffuse_color = cadd(diffuse_color, cmul(cmul_col(col, tcol), light_power * ob.roughness));
         }
         diffuse_color = cdiv(diffuse_color, (float)p.diffuse_scatt);
-        color = cadd(color, Col{0.0f, 0.0f, 0.0f});  // the mirror term of a surface that reflects nothing
+        color = cadd(color, reflect_color);
         color = cadd(color, diffuse_color);
         color = gamma22(color);
     } else {
@@ -1964,7 +2108,7 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 
 // Waves a persistent launch starts: every wave slot of the device (256 CUs x 32), or fewer for a
 // small batch.
-static inline unsigned persistent_grid(uint64_t n) { return (unsigned)std::min<uint64_t>(8192, (n + 63) / 64); }
+static inline unsigned persistent_grid(uint64_t n) { return (unsigned)std::min<uint64_t>(RT_WALK_MAX_GRID, (n + 63) / 64); }
 
 hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, uint32_t* d_counter,
                          hipStream_t s) {
@@ -1975,7 +2119,7 @@ hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, 
         const char* e = std::getenv("RAYS_HIP_TRACE");
         return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'w' ? 2 : 0));
     }();
-    if (walk == 0 && d_counter && n < 0xFFFF0000ull)
+    if (walk == 0 && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
         hipLaunchKernelGGL(k_trace_closest_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_out);
     else if (walk == 2)
@@ -1993,7 +2137,7 @@ hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint
         const char* e = std::getenv("RAYS_HIP_TRACE");
         return e && e[0] == 'l';
     }();
-    if (!lane_walk && d_counter && n < 0xFFFF0000ull)
+    if (!lane_walk && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
         hipLaunchKernelGGL(k_trace_any_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_occ);
     else
@@ -2091,27 +2235,30 @@ hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint3
     return hipGetLastError();
 }
 
-hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                     uint32_t n_rays, uint32_t* d_counter, const float4* d_samp, const uint32_t* d_state,
-                     float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys, DevStats* d_stats,
-                     hipStream_t s) {
-    if (n_rays == 0) return hipSuccess;
+hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const RayTree& tr,
+                     uint32_t level, const uint32_t* d_tile_list, uint32_t* d_counter, const float4* d_samp,
+                     const uint32_t* d_state, float4* d_dsamp, uint32_t* d_dstate, uint32_t* d_dkeys,
+                     uint32_t* d_queues, uint32_t* d_counts, DevStats* d_stats, hipStream_t s) {
+    if (tr.level_rays == 0 || level >= tr.levels) return hipSuccess;
+    if (tr.level_rays >= (1ull << 32) - RT_WALK_HEADROOM) return hipErrorInvalidValue;
+    const dim3 grid(persistent_grid(tr.level_rays));
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_bounce<true>), dim3(persistent_grid(n_rays)), dim3(64), 0, s, sv, p, lp, d_tile_list,
-                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_stats);
+        hipLaunchKernelGGL((k_wf_bounce<true>), grid, dim3(64), 0, s, sv, p, lp, tr, level, d_tile_list, d_counter,
+                           d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_queues, d_counts, d_stats);
     else
-        hipLaunchKernelGGL((k_wf_bounce<false>), dim3(persistent_grid(n_rays)), dim3(64), 0, s, sv, p, lp, d_tile_list,
-                           n_rays, d_counter, d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_stats);
+        hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(64), 0, s, sv, p, lp, tr, level, d_tile_list, d_counter,
+                           d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_queues, d_counts, d_stats);
     return hipGetLastError();
 }
 
-hipError_t wf_resolve_diffuse(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list,
-                              const float4* d_samp, const uint32_t* d_state, const float4* d_dsamp,
-                              const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s) {
+hipError_t wf_resolve_tree(const SceneView& sv, const DevRenderParams& p, const RayTree& tr,
+                           const uint32_t* d_tile_list, const float4* d_samp, const uint32_t* d_state,
+                           const float4* d_dsamp, const uint32_t* d_dstate, uint8_t* d_rgba8, uint32_t* d_hit_ids,
+                           hipStream_t s) {
     const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_wf_resolve_diffuse<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_samp,
-                       d_state, d_dsamp, d_dstate, d_rgba8, d_hit_ids);
+    hipLaunchKernelGGL((k_wf_resolve_tree<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, tr, d_tile_list,
+                       d_samp, d_state, d_dsamp, d_dstate, d_rgba8, d_hit_ids);
     return hipGetLastError();
 }
 

@@ -122,6 +122,10 @@ class World {
     rt_scene* scene_ = nullptr;
 };
 
+// The animated sun of src/main.rs:476-484 at t seconds after start: a circle of radius 100,000 about
+// the y axis at height 25,000.
+Vec3 sun_at(float t);
+
 // The default scene of src/main.rs:406-448: two teapots and a two-triangle floor.
 void default_scene(const std::string& teapot_obj, World* world);
 

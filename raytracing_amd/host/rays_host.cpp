@@ -230,6 +230,10 @@ void World::draw(std::vector<uint8_t>& frame, const FrameParams& fp) {
 
 uint32_t World::num_tris() const { return rt_scene_num_tris(scene_); }
 
+Vec3 sun_at(float t) {
+    return Vec3{std::sin(t / 10.0f) * 100000.0f, 25000.0f, std::cos(t / 10.0f) * 100000.0f};
+}
+
 void default_scene(const std::string& teapot_obj, World* world) {
     std::vector<Triangle> t;
     std::vector<TriangleData> d;

@@ -11,6 +11,16 @@ import numpy as np
 from . import _ffi
 
 SUN_T0 = (0.0, 25000.0, 100000.0)  # src/main.rs:479-483 at t = 0
+
+
+def sun_at(t):
+    """The animated sun of src/main.rs:476-484: a circle of radius 100,000 about the y axis at
+    height 25,000, one turn every 20 pi seconds; single precision as in the reference."""
+    a = np.float32(t) / np.float32(10.0)
+    return (float(np.sin(a, dtype=np.float32) * np.float32(100000.0)), 25000.0,
+            float(np.cos(a, dtype=np.float32) * np.float32(100000.0)))
+
+
 TEAPOT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "teapot.obj")
 
 

@@ -198,6 +198,31 @@ def test_render_default_scene_full_recursion(teapot_pair):
     print(f"full recursion: max diff {d.max()}, share > 1 LSB {(d > 1).mean():.2e}")
 
 
+@pytest.mark.parametrize("reflect_depth", [2, 4, 6])
+def test_render_default_scene_tree_pipeline_equals_one_kernel_frame(teapot_pair, monkeypatch, reflect_depth):
+    """Diffuse scattering over a scene with mirrors runs level by level (scatter and mirror rays off
+    the camera ray's hit, then mirror bounces off their hits, ...). Byte for byte the frame of the
+    one-kernel path, whole, in several runs of tiles, and in shards."""
+    g, _ = teapot_pair
+    W, H = 200, 120
+    kw = dict(reflect_depth=reflect_depth, diffuse_depth=2, seed=99)
+    p = render_params(W, H, 2, **kw)
+    rgba, ids = g.render(p, want_hit_ids=True)
+    monkeypatch.setenv("RAYS_HIP_BOUNCE_RAYS", str(5 * 1024 * 4 * 11))
+    rgba_runs, ids_runs = g.render(p, want_hit_ids=True)
+    assert np.array_equal(rgba_runs, rgba) and np.array_equal(ids_runs, ids)
+    monkeypatch.delenv("RAYS_HIP_BOUNCE_RAYS")
+    monkeypatch.setenv("RAYS_HIP_MEGAKERNEL", "1")
+    rgba_one, ids_one = g.render(p, want_hit_ids=True)
+    monkeypatch.delenv("RAYS_HIP_MEGAKERNEL")
+    assert np.array_equal(ids_one, ids)
+    assert np.array_equal(rgba_one, rgba), f"{(rgba_one != rgba).sum()} bytes differ from the one-kernel frame"
+    acc = np.zeros_like(rgba)
+    for r in range(3):
+        acc |= g.render(render_params(W, H, 2, shard_index=r, shard_count=3, **kw))
+    assert np.array_equal(acc, rgba)
+
+
 def test_render_soup_primary_and_shadow(soup_pair):
     g, o = soup_pair
     W, H = 256, 144
@@ -237,6 +262,48 @@ def test_render_soup_diffuse_bounce_pipeline(soup_pair, monkeypatch):
     for r in range(2):
         acc |= g.render(render_params(W, H, 2, shard_index=r, shard_count=2, **kw))
     assert np.array_equal(acc, rgba)
+
+
+# Quarter, half and three-quarter turns of the reference's animated sun (src/main.rs:476-484) put
+# it on every side of the scene, so the shadow rays' light-space order runs across z, x, -z and -x.
+@pytest.mark.parametrize("t", [7.854, 15.708, 31.416, 47.124, 55.0])
+def test_render_animated_sun_default_scene(teapot_pair, t):
+    g, o = teapot_pair
+    W, H = 320, 180
+    sun = scenes.sun_at(t)
+    kw = dict(reflect_depth=1, diffuse_depth=1, sun=sun)
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
+    rgba, ids = g.render(render_params(W, H, 2, **kw), want_hit_ids=True)
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
+
+
+@pytest.mark.parametrize("sun", [
+    scenes.sun_at(15.708), scenes.sun_at(40.0),
+    (10.0, 100000.0, -20.0),    # straight above: y is the light's dominant axis
+    (0.0, -100000.0, 0.0),      # below everything
+    (0.5, 0.5, 15.0),           # inside the cloud of triangles: hit points lie on every side of it
+    (0.0, 0.0, 0.0),            # at the camera
+])
+def test_render_soup_light_positions(soup_pair, sun):
+    g, o = soup_pair
+    W, H = 224, 128
+    kw = dict(reflect_depth=1, diffuse_depth=1, sun=sun)
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
+    rgba, ids = g.render(render_params(W, H, 2, **kw), want_hit_ids=True)
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
+
+
+def test_render_soup_diffuse_pipeline_with_the_sun_aside(soup_pair):
+    g, o = soup_pair
+    W, H = 64, 64
+    kw = dict(reflect_depth=4, diffuse_depth=2, sun=scenes.sun_at(15.708), seed=7)
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
+    rgba, ids = g.render(render_params(W, H, 2, **kw), want_hit_ids=True)
+    same = ids == ref_ids
+    assert 1.0 - same.mean() <= 1e-5
+    ok = same.reshape(-1, 4).all(axis=1).reshape(ref_rgba.shape[:2])
+    d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16))[ok]
+    assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
 
 
 @pytest.mark.parametrize("grid", [1, 4, 8])
