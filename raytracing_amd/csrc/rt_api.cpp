@@ -336,10 +336,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         tr.mirror = (reflective && p->reflect_depth > 1) ? 1u : 0u;
         tr.branches = tr.scatt + tr.mirror;
         tr.levels = tr.mirror ? p->reflect_depth - 1 : 1u;
-        // Secondary-ray records per run of tiles (64 Mi: 2.3 GB of workspace); RAYS_HIP_BOUNCE_RAYS overrides.
+        // Secondary-ray records per run of tiles: at most 256 Mi (9 GB of workspace, allocated as far as
+        // a frame needs it); RAYS_HIP_BOUNCE_RAYS overrides. Fewer, larger runs are faster: the short
+        // last run of a frame fills the device badly.
         const char* e = std::getenv("RAYS_HIP_BOUNCE_RAYS");
         const long long v = e ? std::atoll(e) : 0;
-        const size_t cap = v > 0 ? (size_t)v : ((size_t)64 << 20);
+        const size_t cap = v > 0 ? (size_t)v : ((size_t)256 << 20);
         const size_t per_tile = (size_t)tile_slots * tr.branches * tr.levels;
         if (per_tile >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays per tile");
         run_tiles = (uint32_t)std::min<size_t>(dp.n_tiles, std::max<size_t>(1, cap / per_tile));
