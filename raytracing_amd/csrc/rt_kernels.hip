@@ -120,6 +120,29 @@ __device__ __forceinline__ bool node_step(const SceneView& sv, uint32_t cur, rt_
     return k0 < RT_INF;
 }
 
+// One triangle record for one ray. Shadow mode returns true if it occludes.
+template <bool ANY>
+__device__ __forceinline__ bool record_test(float4 ra, float4 rb, float4 rc, uint32_t obj_index, rt_f3 o, rt_f3 d,
+                                            float& closest, uint32_t& local_best, HitD& hit) {
+    const rt_f3 v0 = f3(ra.x, ra.y, ra.z);
+    const rt_f3 e1 = f3(ra.w, rb.x, rb.y);
+    const rt_f3 e2 = f3(rb.z, rb.w, rc.x);
+    const uint32_t id = __float_as_uint(rc.y);
+    const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+    if (ANY) return !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t);
+    const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
+    if (!ev.failed && ev.t > 0.0f && better) {
+        closest = ev.t;
+        local_best = id;
+        hit.tri = id;
+        hit.obj = obj_index;
+        hit.t = ev.t;
+        hit.u = ev.u;
+        hit.v = ev.v;
+    }
+    return false;
+}
+
 // One leaf for one ray. Shadow mode returns true at the first occluder.
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool leaf_step(const SceneView& sv, uint32_t cur, uint32_t obj_index, rt_f3 o, rt_f3 d,
@@ -128,30 +151,8 @@ __device__ __forceinline__ bool leaf_step(const SceneView& sv, uint32_t cur, uin
     const uint32_t n = (cur & 7u) + 1u;
     for (uint32_t i = 0; i < n; ++i) {
         const float4* r = sv.recs + 3 * (size_t)(first + i);
-        const float4 ra = r[0], rb = r[1], rc = r[2];
-        const rt_f3 v0 = f3(ra.x, ra.y, ra.z);
-        const rt_f3 e1 = f3(ra.w, rb.x, rb.y);
-        const rt_f3 e2 = f3(rb.z, rb.w, rc.x);
-        const uint32_t id = __float_as_uint(rc.y);
-        if (STATS) {
-            st.tri += 1;
-            st.bytes += 48;
-        }
-        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
-        if (ANY) {
-            if (!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) return true;
-        } else {
-            const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
-            if (!ev.failed && ev.t > 0.0f && better) {
-                closest = ev.t;
-                local_best = id;
-                hit.tri = id;
-                hit.obj = obj_index;
-                hit.t = ev.t;
-                hit.u = ev.u;
-                hit.v = ev.v;
-            }
-        }
+        if (STATS) st.tri += 1, st.bytes += 48;
+        if (record_test<ANY>(r[0], r[1], r[2], obj_index, o, d, closest, local_best, hit)) return true;
     }
     return false;
 }

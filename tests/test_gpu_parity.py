@@ -198,7 +198,7 @@ def test_render_default_scene_full_recursion(teapot_pair):
     print(f"full recursion: max diff {d.max()}, share > 1 LSB {(d > 1).mean():.2e}")
 
 
-@pytest.mark.parametrize("reflect_depth", [2, 4, 6])
+@pytest.mark.parametrize("reflect_depth", [2, 4, 9])
 def test_render_default_scene_tree_pipeline_equals_one_kernel_frame(teapot_pair, monkeypatch, reflect_depth):
     """Diffuse scattering over a scene with mirrors runs level by level (scatter and mirror rays off
     the camera ray's hit, then mirror bounces off their hits, ...). Byte for byte the frame of the

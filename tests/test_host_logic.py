@@ -332,3 +332,15 @@ def test_host_tree_builder_invariants(bvh_shim, kind, n, width):
 
 def rtb_max_leaf():
     return 4
+
+
+def test_sun_at_follows_the_reference_circle():
+    """src/main.rs:476-484: (sin(t / 10) * 100000, 25000, cos(t / 10) * 100000) in single precision."""
+    from raytracing_amd import scenes
+    assert scenes.sun_at(0.0) == scenes.SUN_T0
+    for t in (1.0, 15.70796, 40.0):
+        x, y, z = scenes.sun_at(t)
+        a = np.float32(t) / np.float32(10.0)
+        assert y == 25000.0
+        assert abs(x - float(np.sin(a)) * 1e5) <= 0.02 and abs(z - float(np.cos(a)) * 1e5) <= 0.02
+        assert abs(np.hypot(x, z) - 1e5) <= 0.05
