@@ -940,7 +940,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // the first occluder and hit.tri != RT_MISS says "occluded".
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_WALK_LDS
-#define RT_WALK_LDS 8
+#define RT_WALK_LDS 12
 #endif
 #ifndef RT_REFILL
 #define RT_REFILL 16
@@ -956,14 +956,43 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #endif
 #define RT_WALK_MAX_GRID 8192u                              // waves of a persistent launch
 #define RT_WALK_HEADROOM (RT_WALK_MAX_GRID * RT_CHUNK + 64u)  // counter overshoot at the end of a launch
-using WalkStack = LaneStackT<RT_WALK_LDS, 64>;
+// Stack of the persistent walk: RT_WALK_LDS entries of 6 bytes in LDS (node reference, and the
+// entry distance cut to its upper 16 bits: rounded towards zero, so an entry is never dropped that
+// the full distance would keep), the rest in private memory. 12 entries per lane of 32 waves are
+// 147 KB of the CU's 160 KB; with 8-byte entries the same LDS held 8, and every entry more that
+// stays out of private memory is worth about 3 % on incoherent rays.
+struct WalkLds {
+    uint32_t refs[RT_WALK_LDS * 64];
+    uint16_t keys[RT_WALK_LDS * 64];
+};
+struct WalkStack {
+    uint32_t* refs;  // &lds.refs[lane]; entry e at refs[e * 64]
+    uint16_t* keys;
+    uint2 spill[RT_STACK_MAX - RT_WALK_LDS];
+    int sp;
+    __device__ __forceinline__ void push(uint32_t node, float tnear) {
+        if (sp < RT_WALK_LDS) {
+            refs[sp * 64] = node;
+            keys[sp * 64] = (uint16_t)(__float_as_uint(tnear) >> 16);
+        } else if (sp < RT_STACK_MAX) {
+            spill[sp - RT_WALK_LDS] = make_uint2(node, __float_as_uint(tnear));
+        }
+        sp = sp < RT_STACK_MAX ? sp + 1 : sp;
+    }
+    __device__ __forceinline__ uint2 pop() {
+        --sp;
+        if (sp < RT_WALK_LDS) return make_uint2(refs[sp * 64], (uint32_t)keys[sp * 64] << 16);
+        return spill[sp - RT_WALK_LDS];
+    }
+};
 
 template <bool ANY, bool STATS, class Source>
 __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_rays, uint32_t* counter,
-                                                const Source& src, uint2* s_stack, LaneStats& st) {
+                                                const Source& src, WalkLds& s_stack, LaneStats& st) {
     const uint32_t lane = threadIdx.x & 63u;
     WalkStack stk;
-    stk.lds = &s_stack[threadIdx.x];
+    stk.refs = &s_stack.refs[threadIdx.x];
+    stk.keys = &s_stack.keys[threadIdx.x];
     stk.sp = 0;
     bool has = false, walking = false, in_obj = false;
     bool exhausted = false;  // wave-uniform: the counter has passed the last ray
@@ -1155,7 +1184,7 @@ struct BatchAnySource {
 __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_trace_any_persistent(SceneView sv, const rt_ray* __restrict__ rays,
                                                                            uint32_t n, uint32_t* __restrict__ counter,
                                                                            uint8_t* __restrict__ out) {
-    __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    __shared__ WalkLds s_stack;
     LaneStats st;
     const BatchAnySource src{rays, out};
     persistent_walk<true, false>(sv, n, counter, src, s_stack, st);
@@ -1164,7 +1193,7 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_trace_any_persistent(Scen
 __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_trace_closest_persistent(SceneView sv, const rt_ray* __restrict__ rays,
                                                                    uint32_t n, uint32_t* __restrict__ counter,
                                                                    rt_hit* __restrict__ out) {
-    __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    __shared__ WalkLds s_stack;
     LaneStats st;
     const BatchSource src{rays, out};
     persistent_walk<false, false>(sv, n, counter, src, s_stack, st);
@@ -1858,7 +1887,7 @@ __device__ __forceinline__ rt_f3 reflect_dir(rt_f3 d, rt_f3 n) { return d - 2.0f
 // hit a mirror. Directions are not stored: they follow from the stored triangle ids along the branch.
 // Records of rays that do not exist: level 0 stores "no hit, no shadow ray" itself, the deeper
 // levels are preset to that before the first launch.
-#define RT_QUEUE_LDS 128  // follow-up rays a wave collects before writing them out (>= 2 * 64 - 1)
+#define RT_QUEUE_LDS 96   // follow-up rays a wave collects: written out from 32 on, and a turn adds at most 64
 struct TreeSource {
     static constexpr bool QUEUES = true;
     const SceneView& sv;
@@ -1934,12 +1963,12 @@ struct TreeSource {
             if (rank == 0) s_q[RT_QUEUE_LDS] = base + (uint32_t)__builtin_popcountll(mask);
         }
     }
-    // Whole wave: writes the collected rays out once there are 64 (or any, at the end), one atomic
-    // per write. A turn adds at most 64, so the list never passes 127.
+    // Whole wave: writes the collected rays out once there are 32 (or any, at the end), one atomic
+    // per write. A turn adds at most 64, so the list never passes 95.
     __device__ __forceinline__ void flush(uint32_t lane, bool all) const {
         if (!next_queue) return;
         const uint32_t n = s_q[RT_QUEUE_LDS];
-        if (n == 0 || (!all && n < 64u)) return;
+        if (n == 0 || (!all && n < 32u)) return;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(next_count, n);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1958,7 +1987,7 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
                                                     uint32_t* dstate, uint32_t* __restrict__ dkeys,
                                                     uint32_t* queues, uint32_t* counts,
                                                     DevStats* __restrict__ stats) {
-    __shared__ uint2 s_stack[RT_WALK_LDS * 64];
+    __shared__ WalkLds s_stack;
     __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
     if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
     LaneStats st;
