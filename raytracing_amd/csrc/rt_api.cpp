@@ -100,6 +100,12 @@ struct rt_ctx {
     }
 };
 
+// True when the environment variable is set and begins with `c`.
+bool env_is(const char* name, char c) {
+    const char* e = std::getenv(name);
+    return e && e[0] == c;
+}
+
 // A zeroed work counter for one launch on `stream` (the caller holds ctx->mu).
 int take_counter(rt_ctx* ctx, hipStream_t stream, uint32_t** out) {
     if (!ctx->d_counters) HIP_TRY(hipMalloc((void**)&ctx->d_counters, rt_ctx::N_COUNTERS * 64));
@@ -117,10 +123,14 @@ struct FrameWork {
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* order = nullptr;  // slot numbers in sorted key order (before the sort: ray queues of the levels)
     uint32_t* counts = nullptr; // rays queued per level of the secondary-ray tree
+    unsigned long long* zbuf = nullptr;  // nearest (t, id) per sample of a frame rendered by projection
+    size_t zbuf_words = 0;
+    float* cam_table = nullptr;  // image-plane coordinates of the sample columns and rows
+    size_t cam_table_floats = 0;
     void* temp = nullptr;
     size_t temp_bytes = 0;
     void release() {
-        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, temp})
+        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }
@@ -131,6 +141,12 @@ struct rt_scene {
     FrameWork work;         // per sample: camera rays and their shadow rays
     FrameWork bounce_work;  // per scatter ray of a run of tiles
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
+    // Camera rays by projection (the camera of src/main.rs:314-330 stands at the origin and looks along
+    // +z): possible when no object has trailing triangles and every triangle lies in front of the
+    // camera; raster_dx / raster_dy are the widest extents of a triangle on the image plane z = 1.
+    bool raster_ok = false;
+    float raster_dx = 0.0f, raster_dy = 0.0f;
+    uint32_t n_tris_total = 0;
     SceneView view{};
     std::vector<void*> device_ptrs;
     uint32_t n_tris = 0;
@@ -291,6 +307,8 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     dp.seed = p->seed;
     dp.tiles_x = ceil_div(p->width, RT_TILE);
     dp.beam_levels = s->wide_depth;
+    dp.shard_index = p->shard_index;
+    dp.shard_count = p->shard_count;
     const uint32_t* d_list = nullptr;
     if (p->shard_count > 1) {
         TileMap* tm = nullptr;
@@ -355,15 +373,48 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     }
     FrameWork& w = s->work;
     FrameWork& bw = s->bounce_work;
+    // Camera rays by projection, unless a triangle would cover more than 2048 blocks of 8 x 8 samples
+    // (one wave steps over a triangle's blocks) or the frame is taller than wide (aspect 0).
+    bool raster = s->raster_ok && !d_stats && p->width >= p->height && !env_is("RAYS_HIP_RASTER", '0');
+    if (raster) {
+        const float aspect = (float)(p->width / p->height);
+        const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
+        const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
+        raster = bx * by <= 2048.0f;
+    }
+    const uint32_t n_packed = s->n_tris_total;
     const uint32_t total_tiles = dp.n_tiles;
     HIP_TRY(mark(0));
+    if (raster) {
+        const size_t words = (size_t)p->width * p->height * spp;
+        if (w.zbuf_words < words) {
+            if (w.zbuf) (void)hipFree(w.zbuf);
+            w.zbuf = nullptr;
+            w.zbuf_words = 0;
+            HIP_TRY(hipMalloc((void**)&w.zbuf, words * 8));
+            w.zbuf_words = words;
+        }
+        const size_t tab = (1 + 2 * s->objects.size()) * ((size_t)p->width + p->height) * p->grid;
+        if (w.cam_table_floats < tab) {
+            if (w.cam_table) (void)hipFree(w.cam_table);
+            w.cam_table = nullptr;
+            w.cam_table_floats = 0;
+            HIP_TRY(hipMalloc((void**)&w.cam_table, tab * 4));
+            w.cam_table_floats = tab;
+        }
+        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, stream));
+    }
     for (uint32_t first = 0; first < total_tiles; first += run_tiles) {
         const bool last_run = first + run_tiles >= total_tiles;
         dp.tile_first = first;
         dp.n_tiles = std::min(run_tiles, total_tiles - first);
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
         const LightProj lp = light_projection(s, p, n_slots);
-        HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, stream));
+        if (raster) {
+            HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], stream));
+        } else {
+            HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, stream));
+        }
         if (last_run) HIP_TRY(mark(1));
         if (primary_stats && d_stats && last_run) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -544,6 +595,26 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
         vert_base += d.n_verts;
     }
     s->n_leaves = (uint32_t)leaf_first.size();
+    s->n_tris_total = tri_base;
+    s->raster_ok = n_objs <= 16;
+    for (uint32_t o = 0; o < n_objs && s->raster_ok; ++o) {
+        const DevObject& ob = s->objects[o];
+        if (ob.n_rest != 0) s->raster_ok = false;
+        for (uint32_t i = 0; i < ob.n_tris && s->raster_ok; ++i) {
+            const uint32_t* t = &tris_all[3 * (size_t)(ob.tri_base + i)];
+            float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+            for (int k = 0; k < 3; ++k) {
+                const float* v = &verts_all[3 * (size_t)t[k]];
+                if (!(v[2] > 0.01f)) s->raster_ok = false;
+                const float px = v[0] / v[2], py = v[1] / v[2];
+                x0 = std::min(x0, px), x1 = std::max(x1, px);
+                y0 = std::min(y0, py), y1 = std::max(y1, py);
+            }
+            if (!(x1 - x0 < INFINITY) || !(y1 - y0 < INFINITY)) s->raster_ok = false;
+            s->raster_dx = std::max(s->raster_dx, x1 - x0);
+            s->raster_dy = std::max(s->raster_dy, y1 - y0);
+        }
+    }
 
     // ---- trees: one per object, over its 8-wide triangles ----------------------------------
     std::vector<rtbvh::Node4> nodes_all;

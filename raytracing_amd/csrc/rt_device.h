@@ -62,6 +62,7 @@ struct DevRenderParams {
     uint32_t tile_first;       // position of the launch's first tile in the frame's (or shard's) tile order
     uint32_t compact;          // 1: write tile-compact output, 0: write the frame in place
     uint32_t beam_levels;      // deepest wide tree of the scene (levels of pending children kept in LDS)
+    uint32_t shard_index, shard_count;  // tile (tx, ty) belongs to shard (tx + ty) % shard_count
 };
 
 // Projection used to order shadow rays: from the sun onto the plane across its dominant axis w.

@@ -1759,6 +1759,220 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     if (STATS) flush_stats(st, stats);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Camera rays by projection. All camera rays leave one point, and the sub-samples form a regular
+// grid on the image plane, so the rays that can meet a triangle are the samples inside the
+// triangle's projected bounding box. Triangle by triangle, the samples of that box are put through
+// the reference's own ray-triangle arithmetic (the same camera_dir, the same tri_intersect, the
+// object's box test of src/main.rs:101), and the nearest hit of a sample is kept as the minimum of
+// (t, triangle id) in one 64-bit word: positive floats order like their bit patterns, and the lower
+// id wins a tie on t, which is the reference's rule (it scans ids upward with a strict compare).
+// Only for scenes whose objects have no trailing n % 8 triangles (those do not lower `closest`,
+// which makes the result depend on the object order) and for triangles in front of the camera.
+// One wave takes RT_RASTER_TRIS consecutive triangles; its lanes are an 8 x 8 block of samples that
+// steps over the box. The triangle's data is the same for all lanes (scalar loads).
+// ---------------------------------------------------------------------------------------------
+#ifndef RT_RASTER_TRIS
+#define RT_RASTER_TRIS 16
+#endif
+#define RT_ZKEY_NONE 0xFFFFFFFFFFFFFFFFull
+
+// Sub-sample number of position (subx, suby) on the n x n grid inside a pixel: the inverse of
+// sample_offset.
+__device__ __forceinline__ uint32_t sample_of(uint32_t grid, uint32_t subx, uint32_t suby) {
+    if (grid == 2) return subx == suby ? subx : (subx ? 3u : 2u);
+    return suby * grid + subx;
+}
+
+// Image-plane coordinates of the sample columns and rows: d = (xx, yy, 1) of camera_dir depends on
+// the sample's column for xx and on its row for yy only. With the origin at zero the object's box
+// test (box_intersection_check) splits the same way: the slab interval along x depends on the column,
+// the one along y on the row, the one along z on nothing. All of it is tabulated once per frame with
+// the very operations of camera_dir and box_intersection_check, which leaves the triangle's own
+// division as the only one in the inner loop.
+// Layout, L = gw + gh lines (gw = width * grid columns first, then gh = height * grid rows):
+//   tab[line]                         xx of a column / yy of a row
+//   tab[L * (1 + 2 * obj) + line]     near end of the object's slab interval along that axis
+//   tab[L * (2 + 2 * obj) + line]     far end
+__global__ void k_camera_table(SceneView sv, DevRenderParams p, float* __restrict__ tab) {
+    const uint32_t g = p.grid, gw = p.width * g, gh = p.height * g, L = gw + gh;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const bool col = i < gw;
+    const uint32_t r = col ? i : i - gw;
+    const float c = col ? camera_dir(p, r / g, 0u, sample_of(g, r % g, 0u)).x
+                        : camera_dir(p, 0u, r / g, sample_of(g, 0u, r % g)).y;
+    tab[i] = c;
+    const float inv = 1.0f / c;
+    for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+        const DevObject& ob = sv.objs[oi];
+        const float lo = col ? ob.bbmin[0] : ob.bbmin[1], hi = col ? ob.bbmax[0] : ob.bbmax[1];
+        const float t1 = (lo - 0.0f) * inv, t2 = (hi - 0.0f) * inv;
+        tab[(size_t)L * (1 + 2 * oi) + i] = g_min(t1, t2);
+        tab[(size_t)L * (2 + 2 * oi) + i] = g_max(t1, t2);
+    }
+}
+
+#ifndef RT_RASTER_ABLATE
+#define RT_RASTER_ABLATE 0
+#endif
+#ifndef RT_RASTER_SPAN
+#define RT_RASTER_SPAN 128
+#endif
+#ifndef RT_RASTER_MARGIN
+#define RT_RASTER_MARGIN 0.25f
+#endif
+__device__ __forceinline__ float bcast(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams p, uint32_t n_tris_total,
+                                                  const float* __restrict__ tab,
+                                                  unsigned long long* __restrict__ zbuf) {
+    __shared__ float s_tab[6][RT_RASTER_SPAN];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g);  // grid is a power of two
+    const float aspect = (float)(p.width / p.height);
+    const int gw = (int)(p.width * g), gh = (int)(p.height * g);
+    const uint32_t L = (uint32_t)(gw + gh);
+    // Lane l < RT_RASTER_TRIS prepares triangle l of the wave: its data, its object and the box of
+    // samples its projection can touch.
+    const uint32_t my_id = blockIdx.x * RT_RASTER_TRIS + lane;
+    const bool mine = lane < RT_RASTER_TRIS && my_id < n_tris_total;
+    rt_f3 me1 = f3(0.0f, 0.0f, 0.0f), me2 = me1, mv0 = me1;
+    int mu0 = 0, mu1 = -1, mw0 = 0, mw1 = -1;
+    uint32_t moi = 0;
+    if (mine) {
+        while (my_id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
+        const float* t9 = sv.tri9 + 9 * (size_t)my_id;
+        me1 = ld3(t9), me2 = ld3(t9 + 3), mv0 = ld3(t9 + 6);
+        const rt_f3 vb = mv0 + me1, vc = mv0 + me2;
+        mu0 = 0, mu1 = gw - 1, mw0 = 0, mw1 = gh - 1;
+        const float zmin = fminf(mv0.z, fminf(vb.z, vc.z));
+        if (zmin > 1e-3f) {
+            // Sample column of image-plane x: xx = (2 (x + o) / W - 1) * aspect, sample index
+            // (x + o) * g - 0.5. The hardware reciprocal will do: the margin covers its error and
+            // the rounding of the projection many times over.
+            const float ax = (float)gw * 0.5f / aspect, ay = (float)gh * 0.5f;
+            const float ia = __builtin_amdgcn_rcpf(mv0.z), ib = __builtin_amdgcn_rcpf(vb.z), ic = __builtin_amdgcn_rcpf(vc.z);
+            const float xa = mv0.x * ia, xb = vb.x * ib, xc = vc.x * ic;
+            const float ya = mv0.y * ia, yb = vb.y * ib, yc = vc.y * ic;
+            const float fu0 = (fminf(xa, fminf(xb, xc)) + aspect) * ax - 0.5f;
+            const float fu1 = (fmaxf(xa, fmaxf(xb, xc)) + aspect) * ax - 0.5f;
+            const float fw0 = (1.0f - fmaxf(ya, fmaxf(yb, yc))) * ay - 0.5f;
+            const float fw1 = (1.0f - fminf(ya, fminf(yb, yc))) * ay - 0.5f;
+            const float lim = 1.0e9f;
+            mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - RT_RASTER_MARGIN, -lim), lim)));
+            mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + RT_RASTER_MARGIN, -lim), lim)));
+            mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - RT_RASTER_MARGIN, -lim), lim)));
+            mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + RT_RASTER_MARGIN, -lim), lim)));
+        }
+    }
+    unsigned long long todo = __ballot(mine && mu0 <= mu1 && mw0 <= mw1);
+    const rt_f3 o = f3(0.0f, 0.0f, 0.0f);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t id = blockIdx.x * RT_RASTER_TRIS + (uint32_t)l;
+        const rt_f3 e1 = f3(bcast(me1.x, l), bcast(me1.y, l), bcast(me1.z, l));
+        const rt_f3 e2 = f3(bcast(me2.x, l), bcast(me2.y, l), bcast(me2.z, l));
+        const rt_f3 v0 = f3(bcast(mv0.x, l), bcast(mv0.y, l), bcast(mv0.z, l));
+        const int u0 = __builtin_amdgcn_readlane(mu0, l), u1 = __builtin_amdgcn_readlane(mu1, l);
+        const int w0 = __builtin_amdgcn_readlane(mw0, l), w1 = __builtin_amdgcn_readlane(mw1, l);
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)moi, l);
+        const DevObject& ob = sv.objs[oi];
+        // The z slab of the object's box test: inv_dir.z = 1 / 1.
+        const float tz1 = (ob.bbmin[2] - 0.0f) * (1.0f / 1.0f), tz2 = (ob.bbmax[2] - 0.0f) * (1.0f / 1.0f);
+        const float nz = g_min(tz1, tz2), fz = g_max(tz1, tz2);
+        const float* near_tab = tab + (size_t)L * (1 + 2 * oi);
+        const float* far_tab = tab + (size_t)L * (2 + 2 * oi);
+        // The table lines of the triangle's box go through LDS (one round trip to memory per
+        // triangle instead of two per block of samples); a box of more than RT_RASTER_SPAN lines
+        // a side reads the table directly.
+        const int ncol = u1 - u0 + 1, nrow = w1 - w0 + 1;
+        const bool staged = ncol <= RT_RASTER_SPAN && nrow <= RT_RASTER_SPAN;
+        if (staged) {
+            for (int i = (int)lane; i < RT_RASTER_SPAN; i += 64) {
+                if (i < ncol) {
+                    s_tab[0][i] = tab[u0 + i];
+                    s_tab[1][i] = near_tab[u0 + i];
+                    s_tab[2][i] = far_tab[u0 + i];
+                }
+                if (i < nrow) {
+                    s_tab[3][i] = tab[gw + w0 + i];
+                    s_tab[4][i] = near_tab[gw + w0 + i];
+                    s_tab[5][i] = far_tab[gw + w0 + i];
+                }
+            }
+        }
+        for (int by = w0; by <= w1; by += 8) {
+            const int sw = by + (int)(lane >> 3);
+            const bool row_ok = sw <= w1;
+            const int swc = row_ok ? sw : w1;
+            float dy, ny, fy;
+            if (staged) dy = s_tab[3][swc - w0], ny = s_tab[4][swc - w0], fy = s_tab[5][swc - w0];
+            else dy = tab[gw + swc], ny = near_tab[gw + swc], fy = far_tab[gw + swc];
+            for (int bx = u0; bx <= u1; bx += 8) {
+                const int su = bx + (int)(lane & 7u);
+                if (su > u1 || !row_ok) continue;
+                // A shard keeps the samples of its own tiles only: tile (tx, ty) belongs to shard (tx + ty) % count.
+                if (p.shard_count > 1 &&
+                    (((uint32_t)su >> gs) / RT_TILE + ((uint32_t)sw >> gs) / RT_TILE) % p.shard_count != p.shard_index)
+                    continue;
+                float dx, nx, fx;
+                if (staged) dx = s_tab[0][su - u0], nx = s_tab[1][su - u0], fx = s_tab[2][su - u0];
+                else dx = tab[su], nx = near_tab[su], fx = far_tab[su];
+                const rt_f3 d = f3(dx, dy, 1.0f);
+                const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+                if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
+                // box_intersection_check (src/objects.rs:322-333) from the tabulated slab intervals.
+                const float t_near = g_max(g_max(nx, ny), nz);
+                const float t_far = g_min(g_min(fx, fy), fz);
+                if (!(g_min(t_near, 0.0f) <= t_far)) continue;
+                const uint32_t x = (uint32_t)su >> gs, y = (uint32_t)sw >> gs;
+                const uint32_t smp = sample_of(g, (uint32_t)su & (g - 1u), (uint32_t)sw & (g - 1u));
+                const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
+                unsigned long long* zp = &zbuf[((size_t)y * p.width + x) * p.spp + smp];
+#if RT_RASTER_ABLATE == 1
+                if (key == 12345ull) *zp = key;
+#elif RT_RASTER_ABLATE == 2
+                if (__builtin_nontemporal_load(zp) > key) atomicMin(zp, key);
+#else
+                atomicMin(zp, key);
+#endif
+            }
+        }
+    }
+}
+
+// The records of the camera rays from the nearest-hit words: what k_wf_primary stores.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRenderParams p, LightProj lp,
+                                                          const uint32_t* __restrict__ tile_list,
+                                                          const unsigned long long* __restrict__ zbuf,
+                                                          float4* __restrict__ samp, uint32_t* __restrict__ state,
+                                                          uint32_t* __restrict__ keys) {
+    const PixelMap<BLOCK> pm(p, tile_list, false);
+    const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    unsigned long long key = RT_ZKEY_NONE;
+    if (pm.inside) key = zbuf[((size_t)pm.y * p.width + pm.x) * p.spp + pm.s];
+    const bool hit_any = key != RT_ZKEY_NONE;
+    HitD hs;
+    hs.tri = hit_any ? (uint32_t)key : 0u;
+    hs.t = hit_any ? __uint_as_float((uint32_t)(key >> 32)) : 0.0f;
+    hs.u = hs.v = 0.0f;
+    hs.obj = 0;
+    while (hs.obj + 1 < sv.n_objs && hs.tri >= sv.objs[hs.obj].tri_base + sv.objs[hs.obj].n_tris) ++hs.obj;
+    const Surface sf = surface_of(sv, hs, o, d);
+    const rt_f3 sun_dir = g_normalize(sun - sf.pos);
+    const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
+    const uint32_t slot = pm.block * BLOCK + threadIdx.x;
+    samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(hit_any ? hs.tri : RT_MISS));
+    state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
+    keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
+}
+
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES RT_WF_WAVES
 #endif
@@ -2239,6 +2453,28 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
     else
         hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_stats);
+    return hipGetLastError();
+}
+
+hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
+                        unsigned long long* d_zbuf, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_zbuf, 0xFF, (size_t)p.width * p.height * p.spp * 8, s);
+    if (e != hipSuccess) return e;
+    if (n_tris_total == 0) return hipSuccess;
+    const uint32_t lines = (p.width + p.height) * p.grid;
+    hipLaunchKernelGGL(k_camera_table, dim3((lines + 255) / 256), dim3(256), 0, s, sv, p, d_table);
+    hipLaunchKernelGGL(k_raster, dim3((n_tris_total + RT_RASTER_TRIS - 1) / RT_RASTER_TRIS), dim3(64), 0, s, sv, p,
+                       n_tris_total, d_table, d_zbuf);
+    return hipGetLastError();
+}
+
+hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const LightProj& lp,
+                          const uint32_t* d_tile_list, const unsigned long long* d_zbuf, float4* d_samp,
+                          uint32_t* d_state, uint32_t* d_keys, hipStream_t s) {
+    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_raster_records<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, lp, d_tile_list, d_zbuf,
+                       d_samp, d_state, d_keys);
     return hipGetLastError();
 }
 
