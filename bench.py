@@ -204,25 +204,37 @@ def main():
         torch.cuda.synchronize()
         frame_ok = bool(torch.equal(whole, full))
     phase_ms = [float(np.mean([elapsed_ms(ev[k], ev[k + 1]) for ev in phase_events])) for k in range(4)]
-    kernel_ms = phase_ms[0]  # the camera-ray kernel, the longest of the frame
-
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total * args.steps / elapsed / 1e6
-        # Roofline of the dominant kernel, the camera-ray kernel (k_wf_primary), per launch.
-        # Algorithmic bytes = what one launch has to move to and from HBM: 24 B written per sample
-        # (hit point + id 16 B, state 4 B, sort key 4 B; camera rays are generated on the device,
-        # 0 B in) + the wide tree, the triangle records and the normals/colours read
-        # once (they fit in L2 / Infinity Cache, so a launch needs them from HBM at most once).
-        # "requested_bytes_per_launch" is what the kernel's loads ask the caches for (32 B per child
-        # box a wave tests + 48 B per triangle record a wave fetches, from the kernel's own counters
-        # in the instrumented build): per-ray structure bytes at the granularity the loads are
-        # issued. Its ratio to `traffic` is the cache amplification.
-        my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
-        n_samples_rank = st["primary_rays"]
+        # Roofline of the frame's longest kernel, per launch. Algorithmic bytes = what the launch has
+        # to move to and from HBM; the tree and the triangle records count once (they fit in L2 /
+        # Infinity Cache, so a launch needs them from HBM at most once). "requested_bytes_per_launch"
+        # is what the kernel's loads ask the caches for (32 B per child box a wave tests + 48 B per
+        # triangle record a wave fetches, from the kernel's own counters in the instrumented build):
+        # per-ray structure bytes at the granularity the loads are issued. Its ratio to `traffic` is
+        # the cache amplification.
         sizes = scene.sizes()
-        alg_bytes = 24 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
-        requested_bytes = 24 * n_samples_rank + st["primary_fetch_bytes"]
+        n_samples_rank = st["primary_rays"]
+        n_shadow_rank = st["rays"] - st["primary_rays"]
+        projected = bool(st["camera_by_projection"])
+        if projected or phase_ms[2] > phase_ms[0]:
+            # k_wf_shadow: the sorted key of every sample slot in (4 B; slots without a shadow ray end
+            # there), per shadow ray its slot number (4 B), hit point (16 B) and state word read and
+            # written back (8 B), the wide tree and the triangle records once.
+            kernel, kernel_ms = "k_wf_shadow", phase_ms[2]
+            per_ray = 4 * n_samples_rank + 28 * n_shadow_rank
+            alg_bytes = per_ray + sizes["wide"] + sizes["recs"]
+            requested_bytes = per_ray + st["fetch_bytes"] - st["primary_fetch_bytes"]
+            my_box, my_tri = st["box_tests"] - st["primary_box_tests"], st["tri_tests"] - st["primary_tri_tests"]
+        else:
+            # k_wf_primary: 24 B written per sample (hit point + id 16 B, state 4 B, sort key 4 B; camera
+            # rays are generated on the device, 0 B in), the wide tree, the triangle records and the
+            # normals/colours once.
+            kernel, kernel_ms = "k_wf_primary", phase_ms[0]
+            alg_bytes = 24 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
+            requested_bytes = 24 * n_samples_rank + st["primary_fetch_bytes"]
+            my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (collected with
@@ -232,8 +244,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pm = json.load(f)
             if world == 1 and (args.tris, args.seed, W, H) == (1_000_000, 0x5EED0001, 3840, 2160):
-                traffic = pm["bytes_per_launch"]
-        except OSError:
+                traffic = pm[kernel]["bytes_per_launch"]
+        except (OSError, KeyError):
             pass
         out = {
             "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays)",
@@ -256,6 +268,7 @@ def main():
                 "tri_tests_per_ray": tri_total / max(1, rays_total),
                 "phase_ms": {"camera_rays": phase_ms[0], "shadow_sort": phase_ms[1], "shadow_rays": phase_ms[2],
                              "resolve": phase_ms[3]},
+                "camera_rays_by": "projection of the triangles onto the sample grid" if projected else "beam walk",
                 "scene_build_s": build_s,
                 "parallelism": f"tiles{world}" if world > 1 else "single",
                 "sharded_frame_equals_whole_frame": frame_ok,
@@ -263,7 +276,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_wf_primary",
+                "kernel": kernel,
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",

@@ -91,6 +91,10 @@ typedef struct {
     uint64_t fetch_bytes; /* bytes of tree nodes and triangle records the loads request: a load
                              shared by a wave counts once, a per-ray load once per ray        */
     uint64_t primary_fetch_bytes;
+    uint64_t camera_by_projection; /* 1: the camera rays were found by projecting the triangles onto the
+                                      sample grid; the primary_* counters then count samples put
+                                      through the triangle test (tri), object box tests (box) and
+                                      blocks of 8 x 8 samples stepped over (node)                  */
 } rt_stats;
 
 /* Number of events rt_render_device_events records. */

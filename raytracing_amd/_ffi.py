@@ -65,6 +65,7 @@ class rt_stats(C.Structure):
         ("primary_node_visits", C.c_uint64),
         ("fetch_bytes", C.c_uint64),
         ("primary_fetch_bytes", C.c_uint64),
+        ("camera_by_projection", C.c_uint64),
     ]
 
 

@@ -285,7 +285,8 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
 // events: null, or RT_RENDER_EVENTS hipEvent_t handles recorded around the phases.
 // primary_stats: null, or receives the counters as they stand after the camera-ray kernel.
 int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
-                  hipStream_t stream, void* const* events = nullptr, DevStats* primary_stats = nullptr) {
+                  hipStream_t stream, void* const* events = nullptr, DevStats* primary_stats = nullptr,
+                  bool* projected = nullptr) {
     auto mark = [&](int k) -> hipError_t {
         return events ? hipEventRecord((hipEvent_t)events[k], stream) : hipSuccess;
     };
@@ -375,7 +376,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     FrameWork& bw = s->bounce_work;
     // Camera rays by projection, unless a triangle would cover more than 2048 blocks of 8 x 8 samples
     // (one wave steps over a triangle's blocks) or the frame is taller than wide (aspect 0).
-    bool raster = s->raster_ok && !d_stats && p->width >= p->height && !env_is("RAYS_HIP_RASTER", '0');
+    bool raster = s->raster_ok && p->width >= p->height && !env_is("RAYS_HIP_RASTER", '0');
     if (raster) {
         const float aspect = (float)(p->width / p->height);
         const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
@@ -383,6 +384,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         raster = bx * by <= 2048.0f;
     }
     const uint32_t n_packed = s->n_tris_total;
+    if (projected) *projected = raster;
     const uint32_t total_tiles = dp.n_tiles;
     HIP_TRY(mark(0));
     if (raster) {
@@ -402,7 +404,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(hipMalloc((void**)&w.cam_table, tab * 4));
             w.cam_table_floats = tab;
         }
-        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, stream));
+        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, d_stats, stream));
     }
     for (uint32_t first = 0; first < total_tiles; first += run_tiles) {
         const bool last_run = first + run_tiles >= total_tiles;
@@ -411,7 +413,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
         const LightProj lp = light_projection(s, p, n_slots);
         if (raster) {
-            HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], stream));
+            HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], d_stats, stream));
         } else {
             HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, stream));
         }
@@ -982,7 +984,8 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     HIP_TRY(tmp.alloc((void**)&d_stats, sizeof(DevStats)));
     HIP_TRY(hipMemset(d_stats, 0, sizeof(DevStats)));
     DevStats hp{};
-    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp);
+    bool projected = false;
+    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp, &projected);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     DevStats h;
@@ -997,6 +1000,7 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     stats->primary_tri_tests = hp.tri_tests;
     stats->primary_node_visits = hp.node_visits;
     stats->primary_fetch_bytes = hp.fetch_bytes;
+    stats->camera_by_projection = projected ? 1u : 0u;
     if (std::getenv("RAYS_HIP_VERBOSE"))
         std::fprintf(stderr,
                      "rays_hip: camera kernel: %llu beam walks, %llu mask walks, %llu refits, %llu mask-walk nodes; "

@@ -34,10 +34,10 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
 // for the tiles of the shard p names; raster_records turns the words of the launch's tiles into the
 // records wf_primary stores. d_table: (1 + 2 * n_objs) * (width + height) * grid floats.
 hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
-                        unsigned long long* d_zbuf, hipStream_t s);
+                        unsigned long long* d_zbuf, DevStats* d_stats, hipStream_t s);
 hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const LightProj& lp,
                           const uint32_t* d_tile_list, const unsigned long long* d_zbuf, float4* d_samp,
-                          uint32_t* d_state, uint32_t* d_keys, hipStream_t s);
+                          uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s);
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
                      DevStats* d_stats, hipStream_t s);

@@ -1813,9 +1813,6 @@ __global__ void k_camera_table(SceneView sv, DevRenderParams p, float* __restric
     }
 }
 
-#ifndef RT_RASTER_ABLATE
-#define RT_RASTER_ABLATE 0
-#endif
 #ifndef RT_RASTER_SPAN
 #define RT_RASTER_SPAN 128
 #endif
@@ -1826,10 +1823,16 @@ __device__ __forceinline__ float bcast(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// Counters of an instrumented run: tri = samples put through the triangle test, box = object box
+// tests, node = blocks of 8 x 8 samples stepped over, bytes = triangle data, table lines and
+// nearest-hit words asked for.
+template <bool STATS>
 __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams p, uint32_t n_tris_total,
                                                   const float* __restrict__ tab,
-                                                  unsigned long long* __restrict__ zbuf) {
+                                                  unsigned long long* __restrict__ zbuf,
+                                                  DevStats* __restrict__ stats) {
     __shared__ float s_tab[6][RT_RASTER_SPAN];
+    LaneStats st;
     const uint32_t lane = threadIdx.x;
     const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g);  // grid is a power of two
     const float aspect = (float)(p.width / p.height);
@@ -1846,6 +1849,7 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
         while (my_id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
         const float* t9 = sv.tri9 + 9 * (size_t)my_id;
         me1 = ld3(t9), me2 = ld3(t9 + 3), mv0 = ld3(t9 + 6);
+        if (STATS) st.bytes += 36;
         const rt_f3 vb = mv0 + me1, vc = mv0 + me2;
         mu0 = 0, mu1 = gw - 1, mw0 = 0, mw1 = gh - 1;
         const float zmin = fminf(mv0.z, fminf(vb.z, vc.z));
@@ -1893,6 +1897,7 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
         const bool staged = ncol <= RT_RASTER_SPAN && nrow <= RT_RASTER_SPAN;
         if (staged) {
             for (int i = (int)lane; i < RT_RASTER_SPAN; i += 64) {
+                if (STATS) st.bytes += 12 * ((i < ncol) + (i < nrow));
                 if (i < ncol) {
                     s_tab[0][i] = tab[u0 + i];
                     s_tab[1][i] = near_tab[u0 + i];
@@ -1914,6 +1919,7 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
             else dy = tab[gw + swc], ny = near_tab[gw + swc], fy = far_tab[gw + swc];
             for (int bx = u0; bx <= u1; bx += 8) {
                 const int su = bx + (int)(lane & 7u);
+                if (STATS && lane == 0) st.node += 1;
                 if (su > u1 || !row_ok) continue;
                 // A shard keeps the samples of its own tiles only: tile (tx, ty) belongs to shard (tx + ty) % count.
                 if (p.shard_count > 1 &&
@@ -1923,8 +1929,10 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
                 if (staged) dx = s_tab[0][su - u0], nx = s_tab[1][su - u0], fx = s_tab[2][su - u0];
                 else dx = tab[su], nx = near_tab[su], fx = far_tab[su];
                 const rt_f3 d = f3(dx, dy, 1.0f);
+                if (STATS) st.tri += 1, st.bytes += staged ? 0 : 12;
                 const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
                 if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
+                if (STATS) st.box += 1, st.bytes += 8;
                 // box_intersection_check (src/objects.rs:322-333) from the tabulated slab intervals.
                 const float t_near = g_max(g_max(nx, ny), nz);
                 const float t_far = g_min(g_min(fx, fy), fz);
@@ -1933,25 +1941,20 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
                 const uint32_t smp = sample_of(g, (uint32_t)su & (g - 1u), (uint32_t)sw & (g - 1u));
                 const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
                 unsigned long long* zp = &zbuf[((size_t)y * p.width + x) * p.spp + smp];
-#if RT_RASTER_ABLATE == 1
-                if (key == 12345ull) *zp = key;
-#elif RT_RASTER_ABLATE == 2
-                if (__builtin_nontemporal_load(zp) > key) atomicMin(zp, key);
-#else
                 atomicMin(zp, key);
-#endif
             }
         }
     }
+    if (STATS) flush_stats(st, stats);
 }
 
 // The records of the camera rays from the nearest-hit words: what k_wf_primary stores.
-template <int BLOCK>
+template <bool STATS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRenderParams p, LightProj lp,
                                                           const uint32_t* __restrict__ tile_list,
                                                           const unsigned long long* __restrict__ zbuf,
                                                           float4* __restrict__ samp, uint32_t* __restrict__ state,
-                                                          uint32_t* __restrict__ keys) {
+                                                          uint32_t* __restrict__ keys, DevStats* __restrict__ stats) {
     const PixelMap<BLOCK> pm(p, tile_list, false);
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
@@ -1971,6 +1974,12 @@ __global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRende
     samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(hit_any ? hs.tri : RT_MISS));
     state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
     keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
+    if (STATS) {
+        LaneStats st;
+        st.rays = pm.inside ? 1u : 0u;
+        st.bytes = pm.inside ? 8u : 0u;
+        flush_stats(st, stats);
+    }
 }
 
 #ifndef RT_SHADOW_WAVES
@@ -2457,24 +2466,29 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
 }
 
 hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
-                        unsigned long long* d_zbuf, hipStream_t s) {
+                        unsigned long long* d_zbuf, DevStats* d_stats, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_zbuf, 0xFF, (size_t)p.width * p.height * p.spp * 8, s);
     if (e != hipSuccess) return e;
     if (n_tris_total == 0) return hipSuccess;
     const uint32_t lines = (p.width + p.height) * p.grid;
     hipLaunchKernelGGL(k_camera_table, dim3((lines + 255) / 256), dim3(256), 0, s, sv, p, d_table);
-    hipLaunchKernelGGL(k_raster, dim3((n_tris_total + RT_RASTER_TRIS - 1) / RT_RASTER_TRIS), dim3(64), 0, s, sv, p,
-                       n_tris_total, d_table, d_zbuf);
+    const dim3 grid((n_tris_total + RT_RASTER_TRIS - 1) / RT_RASTER_TRIS);
+    if (d_stats) hipLaunchKernelGGL(k_raster<true>, grid, dim3(64), 0, s, sv, p, n_tris_total, d_table, d_zbuf, d_stats);
+    else hipLaunchKernelGGL(k_raster<false>, grid, dim3(64), 0, s, sv, p, n_tris_total, d_table, d_zbuf, d_stats);
     return hipGetLastError();
 }
 
 hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const LightProj& lp,
                           const uint32_t* d_tile_list, const unsigned long long* d_zbuf, float4* d_samp,
-                          uint32_t* d_state, uint32_t* d_keys, hipStream_t s) {
+                          uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s) {
     const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_raster_records<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, lp, d_tile_list, d_zbuf,
-                       d_samp, d_state, d_keys);
+    if (d_stats)
+        hipLaunchKernelGGL((k_raster_records<true, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, lp, d_tile_list,
+                           d_zbuf, d_samp, d_state, d_keys, d_stats);
+    else
+        hipLaunchKernelGGL((k_raster_records<false, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, lp, d_tile_list,
+                           d_zbuf, d_samp, d_state, d_keys, d_stats);
     return hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ pub struct rt_stats {
     pub primary_node_visits: u64,
     pub fetch_bytes: u64,
     pub primary_fetch_bytes: u64,
+    pub camera_by_projection: u64,
 }
 
 extern "C" {
