@@ -306,6 +306,87 @@ def test_render_soup_diffuse_pipeline_with_the_sun_aside(soup_pair):
     assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
 
 
+def _stats(g, p):
+    import torch
+
+    frame = torch.zeros((p.height, p.width, 4), dtype=torch.uint8, device="cuda")
+    return g.render_device_stats(p, frame.data_ptr())
+
+
+@pytest.mark.parametrize("size,grid", [((256, 144), 2), ((333, 200), 2), ((200, 200), 4), ((96, 64), 8), ((160, 90), 1)])
+def test_camera_rays_by_projection_equal_the_beam_walk(soup_pair, monkeypatch, size, grid):
+    """Scenes without trailing triangles find their camera rays by projecting the triangles onto the
+    sample grid. Same frame and the same hit ids as the tree walk, whole and in shards."""
+    g, _ = soup_pair
+    W, H = size
+    kw = dict(reflect_depth=1, diffuse_depth=1)
+    p = render_params(W, H, grid, **kw)
+    assert _stats(g, p)["camera_by_projection"] == 1
+    rgba, ids = g.render(p, want_hit_ids=True)
+    acc = np.zeros_like(rgba)
+    for r in range(3):
+        acc |= g.render(render_params(W, H, grid, shard_index=r, shard_count=3, **kw))
+    assert np.array_equal(acc, rgba)
+    monkeypatch.setenv("RAYS_HIP_RASTER", "0")
+    assert _stats(g, p)["camera_by_projection"] == 0
+    rgba_walk, ids_walk = g.render(p, want_hit_ids=True)
+    assert np.array_equal(ids_walk, ids), f"{(ids_walk != ids).sum()} hit ids differ"
+    assert np.array_equal(rgba_walk, rgba)
+
+
+def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k):
+    """Two objects with the same triangles: every hit ties on t between them, and the reference's
+    strict compare leaves the hit with the first object."""
+    a = dict(soup64k[0])
+    b = dict(soup64k[0])
+    b["material"] = (0.2, 0.0, 1.0)
+    objs = [a, b]
+    g, o = Scene(ctx, objs), oracle.OracleScene(objs)
+    W, H = 192, 108
+    kw = dict(reflect_depth=1, diffuse_depth=1)
+    p = render_params(W, H, 2, **kw)
+    assert _stats(g, p)["camera_by_projection"] == 1
+    ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
+    rgba, ids = g.render(p, want_hit_ids=True)
+    hit = ids != RT_MISS
+    assert hit.any() and (ids[hit] < 65536).all()
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
+    g.close()
+
+
+def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, monkeypatch):
+    """Trailing triangles, triangles at or behind the camera plane, triangles that would cover a large
+    part of the frame and frames taller than wide take the tree walk."""
+    p = render_params(128, 72, 2, reflect_depth=1, diffuse_depth=1)
+    g = Scene(ctx, default_objects)          # the floor is two trailing triangles
+    assert _stats(g, p)["camera_by_projection"] == 0
+    g.close()
+    behind = dict(soup64k[0])
+    v = behind["verts"].copy()
+    v[:3, 2] = -1.0                          # first triangle behind the camera
+    behind["verts"] = v
+    g = Scene(ctx, [behind])
+    assert _stats(g, p)["camera_by_projection"] == 0
+    g.close()
+    big = dict(soup64k[0])
+    v = big["verts"].copy()
+    v[:3] = np.array([[-40.0, -40.0, 20.0], [40.0, -40.0, 20.0], [0.0, 40.0, 20.0]], dtype=np.float32)
+    big["verts"] = v
+    g = Scene(ctx, [big])
+    small = render_params(64, 36, 2, reflect_depth=1, diffuse_depth=1)
+    assert _stats(g, small)["camera_by_projection"] == 1                   # 128 x 72 samples: 680 blocks at most
+    rgba, ids = g.render(small, want_hit_ids=True)
+    monkeypatch.setenv("RAYS_HIP_RASTER", "0")
+    rgba_walk, ids_walk = g.render(small, want_hit_ids=True)
+    monkeypatch.delenv("RAYS_HIP_RASTER")
+    assert np.array_equal(ids_walk, ids) and np.array_equal(rgba_walk, rgba)
+    assert _stats(g, render_params(3840, 2160, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 0
+    g.close()
+    g = Scene(ctx, soup64k)
+    assert _stats(g, render_params(72, 128, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 0
+    g.close()
+
+
 @pytest.mark.parametrize("grid", [1, 4, 8])
 def test_render_other_sample_grids(soup_pair, grid):
     """n x n sub-samples per pixel other than the reference's 2 x 2: 1, 16 and 64 samples."""
