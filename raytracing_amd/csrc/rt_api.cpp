@@ -146,6 +146,7 @@ struct rt_scene {
     // camera; raster_dx / raster_dy are the widest extents of a triangle on the image plane z = 1.
     bool raster_ok = false;
     float raster_dx = 0.0f, raster_dy = 0.0f;
+    double raster_sum_dx = 0.0, raster_sum_dy = 0.0, raster_sum_area = 0.0;  // over all triangles
     uint32_t n_tris_total = 0;
     SceneView view{};
     std::vector<void*> device_ptrs;
@@ -382,6 +383,22 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
         const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
         raster = bx * by <= 2048.0f;
+        // Its work grows with the summed area of the triangles' boxes (every layer of depth is
+        // tested), the tree walk's with the number of samples. Projection is taken while its
+        // estimate stays at or below 64 sample slots per sample of the frame; measured camera +
+        // shadow frames, projection against tree walk: 1 M triangles at 3840 x 2160 (estimate 29)
+        // 4.1 / 5.8 ms, at 960 x 540 (67) 1.27 / 1.40 ms; 3 M at 3840 x 2160 (87) 6.0 / 5.3 ms;
+        // 10 M (291) 13.2 / 5.2 ms.
+        const double sx = (double)(p->width * p->grid) * 0.5 / aspect / 8.0, sy = (double)(p->height * p->grid) * 0.5 / 8.0;
+        // Blocks of 8 x 8 samples: a box of w samples takes about w / 8 + 0.7 blocks a side.
+        const double blocks = sx * sy * s->raster_sum_area + 0.7 * sx * s->raster_sum_dx + 0.7 * sy * s->raster_sum_dy +
+                              0.49 * (double)s->n_tris_total;
+        const double ratio = blocks * 64.0 / ((double)p->width * p->height * spp);
+        const char* lim_env = std::getenv("RAYS_HIP_RASTER_RATIO");
+        const double limit = lim_env ? std::atof(lim_env) : 64.0;
+        if (std::getenv("RAYS_HIP_VERBOSE"))
+            std::fprintf(stderr, "rays_hip: projection would test %.1f sample slots per sample (limit %.1f)\n", ratio, limit);
+        raster = raster && ratio <= limit;
     }
     const uint32_t n_packed = s->n_tris_total;
     if (projected) *projected = raster;
@@ -615,6 +632,9 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             if (!(x1 - x0 < INFINITY) || !(y1 - y0 < INFINITY)) s->raster_ok = false;
             s->raster_dx = std::max(s->raster_dx, x1 - x0);
             s->raster_dy = std::max(s->raster_dy, y1 - y0);
+            s->raster_sum_dx += x1 - x0;
+            s->raster_sum_dy += y1 - y0;
+            s->raster_sum_area += (double)(x1 - x0) * (y1 - y0);
         }
     }
 

@@ -321,6 +321,8 @@ def test_camera_rays_by_projection_equal_the_beam_walk(soup_pair, monkeypatch, s
     W, H = size
     kw = dict(reflect_depth=1, diffuse_depth=1)
     p = render_params(W, H, grid, **kw)
+    # 65,536 triangles over so few samples would be left to the tree walk; lift the work limit.
+    monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
     assert _stats(g, p)["camera_by_projection"] == 1
     rgba, ids = g.render(p, want_hit_ids=True)
     acc = np.zeros_like(rgba)
@@ -334,7 +336,7 @@ def test_camera_rays_by_projection_equal_the_beam_walk(soup_pair, monkeypatch, s
     assert np.array_equal(rgba_walk, rgba)
 
 
-def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k):
+def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k, monkeypatch):
     """Two objects with the same triangles: every hit ties on t between them, and the reference's
     strict compare leaves the hit with the first object."""
     a = dict(soup64k[0])
@@ -345,6 +347,7 @@ def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k):
     W, H = 192, 108
     kw = dict(reflect_depth=1, diffuse_depth=1)
     p = render_params(W, H, 2, **kw)
+    monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
     assert _stats(g, p)["camera_by_projection"] == 1
     ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
     rgba, ids = g.render(p, want_hit_ids=True)
@@ -356,8 +359,14 @@ def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k):
 
 def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, monkeypatch):
     """Trailing triangles, triangles at or behind the camera plane, triangles that would cover a large
-    part of the frame and frames taller than wide take the tree walk."""
+    part of the frame, frames taller than wide and frames with few samples for the scene's triangles
+    take the tree walk."""
     p = render_params(128, 72, 2, reflect_depth=1, diffuse_depth=1)
+    g = Scene(ctx, soup64k)
+    assert _stats(g, p)["camera_by_projection"] == 0                        # 65,536 triangles, 36,864 samples
+    assert _stats(g, render_params(1920, 1080, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 1
+    g.close()
+    monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
     g = Scene(ctx, default_objects)          # the floor is two trailing triangles
     assert _stats(g, p)["camera_by_projection"] == 0
     g.close()
