@@ -206,6 +206,7 @@ int check_render_params(const rt_render_params* p, uint32_t* spp) {
         return fail(RT_ERR_UNSUPPORTED, "reflect_depth above %d is not supported", RT_MAX_REFLECT + 1);
     if (p->diffuse_depth > 2) return fail(RT_ERR_UNSUPPORTED, "diffuse_depth above 2 is not supported");
     if (p->diffuse_depth > 1 && p->diffuse_scatt == 0) return fail(RT_ERR_INVALID, "diffuse_scatt is zero");
+    if (p->shard_count > 4096) return fail(RT_ERR_UNSUPPORTED, "more than 4096 shards");
     if (p->shard_count == 0 || p->shard_index >= p->shard_count)
         return fail(RT_ERR_INVALID, "shard_index %u out of range for shard_count %u", p->shard_index, p->shard_count);
     *spp = p->grid * p->grid;
@@ -311,6 +312,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     dp.beam_levels = s->wide_depth;
     dp.shard_index = p->shard_index;
     dp.shard_count = p->shard_count;
+    dp.shard_magic = (uint32_t)(((1ull << 32) + p->shard_count - 1) / p->shard_count);
     const uint32_t* d_list = nullptr;
     if (p->shard_count > 1) {
         TileMap* tm = nullptr;

@@ -63,6 +63,7 @@ struct DevRenderParams {
     uint32_t compact;          // 1: write tile-compact output, 0: write the frame in place
     uint32_t beam_levels;      // deepest wide tree of the scene (levels of pending children kept in LDS)
     uint32_t shard_index, shard_count;  // tile (tx, ty) belongs to shard (tx + ty) % shard_count
+    uint32_t shard_magic;               // 2^32 / shard_count rounded up: x / count = (x * magic) >> 32 for x < 2^16
 };
 
 // Projection used to order shadow rays: from the sun onto the plane across its dominant axis w.

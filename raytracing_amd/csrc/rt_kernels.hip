@@ -1821,6 +1821,22 @@ __global__ void k_camera_table(SceneView sv, DevRenderParams p, float* __restric
 #ifndef RT_RASTER_MARGIN
 #define RT_RASTER_MARGIN 0.25f
 #endif
+// True when the shard owns one of the tiles that the sample rectangle [u0, u1] x [w0, w1] touches
+// (tile (tx, ty) belongs to shard (tx + ty) % count). gs = log2(samples per pixel side).
+__device__ __forceinline__ bool shard_touches(const DevRenderParams& p, uint32_t gs, int u0, int u1, int w0, int w1) {
+    if (p.shard_count <= 1) return true;
+    const uint32_t tx0 = ((uint32_t)u0 >> gs) / RT_TILE, tx1 = ((uint32_t)u1 >> gs) / RT_TILE;
+    const uint32_t ty0 = ((uint32_t)w0 >> gs) / RT_TILE, ty1 = ((uint32_t)w1 >> gs) / RT_TILE;
+    // A run of `count` consecutive diagonals holds every shard.
+    if (tx1 - tx0 + ty1 - ty0 + 1 >= p.shard_count) return true;
+    // dsum % count through the reciprocal the host prepared (tile sums stay far below 2^16).
+    for (uint32_t dsum = tx0 + ty0; dsum <= tx1 + ty1; ++dsum) {
+        const uint32_t q = (uint32_t)(((uint64_t)dsum * p.shard_magic) >> 32);
+        if (dsum - q * p.shard_count == p.shard_index) return true;
+    }
+    return false;
+}
+
 __device__ __forceinline__ float bcast(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -1874,7 +1890,8 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
             mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + RT_RASTER_MARGIN, -lim), lim)));
         }
     }
-    unsigned long long todo = __ballot(mine && mu0 <= mu1 && mw0 <= mw1);
+    unsigned long long todo =
+        __ballot(mine && mu0 <= mu1 && mw0 <= mw1 && shard_touches(p, gs, mu0, mu1, mw0, mw1));
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f);
     while (todo) {
         const int l = __builtin_ctzll(todo);
@@ -1920,13 +1937,13 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
             if (staged) dy = s_tab[3][swc - w0], ny = s_tab[4][swc - w0], fy = s_tab[5][swc - w0];
             else dy = tab[gw + swc], ny = near_tab[gw + swc], fy = far_tab[gw + swc];
             for (int bx = u0; bx <= u1; bx += 8) {
+                // Blocks on other shards' tiles are passed over by the whole wave.
+                if (!shard_touches(p, gs, bx, min(bx + 7, u1), by, min(by + 7, w1))) continue;
                 const int su = bx + (int)(lane & 7u);
                 if (STATS && lane == 0) st.node += 1;
                 if (su > u1 || !row_ok) continue;
                 // A shard keeps the samples of its own tiles only: tile (tx, ty) belongs to shard (tx + ty) % count.
-                if (p.shard_count > 1 &&
-                    (((uint32_t)su >> gs) / RT_TILE + ((uint32_t)sw >> gs) / RT_TILE) % p.shard_count != p.shard_index)
-                    continue;
+                if (!shard_touches(p, gs, su, su, sw, sw)) continue;
                 float dx, nx, fx;
                 if (staged) dx = s_tab[0][su - u0], nx = s_tab[1][su - u0], fx = s_tab[2][su - u0];
                 else dx = tab[su], nx = near_tab[su], fx = far_tab[su];
