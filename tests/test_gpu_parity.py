@@ -198,7 +198,7 @@ def test_render_default_scene_full_recursion(teapot_pair):
     print(f"full recursion: max diff {d.max()}, share > 1 LSB {(d > 1).mean():.2e}")
 
 
-@pytest.mark.parametrize("reflect_depth", [2, 4, 9])
+@pytest.mark.parametrize("reflect_depth", [1, 2, 4, 9])
 def test_render_default_scene_tree_pipeline_equals_one_kernel_frame(teapot_pair, monkeypatch, reflect_depth):
     """Diffuse scattering over a scene with mirrors runs level by level (scatter and mirror rays off
     the camera ray's hit, then mirror bounces off their hits, ...). Byte for byte the frame of the
@@ -304,6 +304,22 @@ def test_render_soup_diffuse_pipeline_with_the_sun_aside(soup_pair):
     ok = same.reshape(-1, 4).all(axis=1).reshape(ref_rgba.shape[:2])
     d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16))[ok]
     assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
+
+
+def test_tree_pipeline_with_a_mirror_no_ray_reaches(ctx, soup64k, monkeypatch):
+    """A mirror in the scene that nothing hits: the deeper levels of the pipeline run on empty queues."""
+    far = scenes.soup(64, 0x5EED0003, material=(1.0, 0.8, 0.2))[0]
+    far = dict(far)
+    far["verts"] = far["verts"] + np.array([0.0, 500.0, -400.0], dtype=np.float32)   # above and behind the camera
+    objs = [soup64k[0], far]
+    g = Scene(ctx, objs)
+    p = render_params(96, 64, 2, reflect_depth=4, diffuse_depth=2, seed=5)
+    rgba, ids = g.render(p, want_hit_ids=True)
+    monkeypatch.setenv("RAYS_HIP_MEGAKERNEL", "1")
+    rgba_one, ids_one = g.render(p, want_hit_ids=True)
+    monkeypatch.delenv("RAYS_HIP_MEGAKERNEL")
+    assert np.array_equal(ids_one, ids) and np.array_equal(rgba_one, rgba)
+    g.close()
 
 
 def _stats(g, p):
