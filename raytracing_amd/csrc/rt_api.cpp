@@ -125,6 +125,7 @@ struct FrameWork {
     uint32_t* counts = nullptr; // rays queued per level of the secondary-ray tree
     unsigned long long* zbuf = nullptr;  // nearest (t, id) per sample of a frame rendered by projection
     size_t zbuf_words = 0;
+    bool zbuf_clean = false;             // every word says "none" (the record pass of a whole frame leaves it so)
     float* cam_table = nullptr;  // image-plane coordinates of the sample columns and rows
     size_t cam_table_floats = 0;
     void* temp = nullptr;
@@ -414,6 +415,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             w.zbuf_words = 0;
             HIP_TRY(hipMalloc((void**)&w.zbuf, words * 8));
             w.zbuf_words = words;
+            w.zbuf_clean = false;
         }
         const size_t tab = (1 + 2 * s->objects.size()) * ((size_t)p->width + p->height) * p->grid;
         if (w.cam_table_floats < tab) {
@@ -423,7 +425,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(hipMalloc((void**)&w.cam_table, tab * 4));
             w.cam_table_floats = tab;
         }
-        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, d_stats, stream));
+        const bool clear = !w.zbuf_clean;
+        w.zbuf_clean = false;  // until the record pass has been through every tile of this frame
+        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, clear, d_stats, stream));
     }
     for (uint32_t first = 0; first < total_tiles; first += run_tiles) {
         const bool last_run = first + run_tiles >= total_tiles;
@@ -479,6 +483,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         }
     }
     HIP_TRY(mark(4));
+    if (raster) w.zbuf_clean = true;
     return RT_OK;
 }
 

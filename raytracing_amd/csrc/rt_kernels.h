@@ -31,12 +31,13 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
 // Camera rays by projection of the triangles onto the sample grid (scenes without trailing
 // triangles, all of them in front of the camera). raster_depth fills d_zbuf (width * height * spp
 // words of 8 bytes: nearest (t, triangle id) per sample, all ones for none) for the whole frame, or
-// for the tiles of the shard p names; raster_records turns the words of the launch's tiles into the
-// records wf_primary stores. d_table: (1 + 2 * n_objs) * (width + height) * grid floats.
+// for the tiles of the shard p names (clear: set every word to "none" first); raster_records turns the
+// words of the launch's tiles into the records wf_primary stores and sets them back to "none", so
+// that a buffer every tile of which has gone through raster_records needs no clearing. d_table: (1 + 2 * n_objs) * (width + height) * grid floats.
 hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
-                        unsigned long long* d_zbuf, DevStats* d_stats, hipStream_t s);
+                        unsigned long long* d_zbuf, bool clear, DevStats* d_stats, hipStream_t s);
 hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const LightProj& lp,
-                          const uint32_t* d_tile_list, const unsigned long long* d_zbuf, float4* d_samp,
+                          const uint32_t* d_tile_list, unsigned long long* d_zbuf, float4* d_samp,
                           uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s);
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,

@@ -1995,18 +1995,23 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
     if (STATS) flush_stats(st, stats);
 }
 
-// The records of the camera rays from the nearest-hit words: what k_wf_primary stores.
+// The records of the camera rays from the nearest-hit words: what k_wf_primary stores. Every word
+// read is set back to "none", so the buffer is ready for the next frame without a pass of its own.
 template <bool STATS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRenderParams p, LightProj lp,
                                                           const uint32_t* __restrict__ tile_list,
-                                                          const unsigned long long* __restrict__ zbuf,
+                                                          unsigned long long* __restrict__ zbuf,
                                                           float4* __restrict__ samp, uint32_t* __restrict__ state,
                                                           uint32_t* __restrict__ keys, DevStats* __restrict__ stats) {
     const PixelMap<BLOCK> pm(p, tile_list, false);
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
     unsigned long long key = RT_ZKEY_NONE;
-    if (pm.inside) key = zbuf[((size_t)pm.y * p.width + pm.x) * p.spp + pm.s];
+    if (pm.inside) {
+        unsigned long long* zp = &zbuf[((size_t)pm.y * p.width + pm.x) * p.spp + pm.s];
+        key = *zp;
+        *zp = RT_ZKEY_NONE;
+    }
     const bool hit_any = key != RT_ZKEY_NONE;
     HitD hs;
     hs.tri = hit_any ? (uint32_t)key : 0u;
@@ -2513,9 +2518,11 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
 }
 
 hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
-                        unsigned long long* d_zbuf, DevStats* d_stats, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(d_zbuf, 0xFF, (size_t)p.width * p.height * p.spp * 8, s);
-    if (e != hipSuccess) return e;
+                        unsigned long long* d_zbuf, bool clear, DevStats* d_stats, hipStream_t s) {
+    if (clear) {
+        hipError_t e = hipMemsetAsync(d_zbuf, 0xFF, (size_t)p.width * p.height * p.spp * 8, s);
+        if (e != hipSuccess) return e;
+    }
     if (n_tris_total == 0) return hipSuccess;
     const uint32_t lines = (p.width + p.height) * p.grid;
     hipLaunchKernelGGL(k_camera_table, dim3((lines + 255) / 256), dim3(256), 0, s, sv, p, d_table);
@@ -2526,7 +2533,7 @@ hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t 
 }
 
 hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const LightProj& lp,
-                          const uint32_t* d_tile_list, const unsigned long long* d_zbuf, float4* d_samp,
+                          const uint32_t* d_tile_list, unsigned long long* d_zbuf, float4* d_samp,
                           uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s) {
     const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
     if (blocks == 0) return hipSuccess;
