@@ -149,6 +149,16 @@ int  rt_trace_closest_device(rt_scene*, const rt_ray* d_rays, uint64_t n, rt_hit
                              void* stream);
 int  rt_trace_any_device(rt_scene*, const rt_ray* d_rays, uint64_t n, uint8_t* d_occluded,
                          void* stream);
+/* rt_trace_closest_device for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc. No counterpart in the reference. Same arguments
+ * and results as rt_trace_closest_device; it calls no hipMalloc / hipFree or any other allocating
+ * routine. The work counter of its kernel lives in a 256-byte file-scope device array that every GPU
+ * the library runs on holds until the process ends (rt_ctx_create looks its address up once per
+ * device). At most 2^31 rays per call (RT_ERR_UNSUPPORTED beyond). Every call on a GPU uses that
+ * GPU's array: calls that overlap on one GPU (different streams, or contexts on the same device)
+ * race; calls on one stream, or ordered by the caller, do not. */
+int  rt_trace_closest_device_noalloc(rt_scene*, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
+                                     void* stream);
 /* The reference's own search order run on the GPU: every 8-triangle leaf box of every object
  * in turn, no tree (src/main.rs:100-171). Slow; exists so that arithmetic parity can be checked
  * apart from tree traversal. Host buffers. */

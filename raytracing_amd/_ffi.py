@@ -88,6 +88,7 @@ SYMBOLS = {
     "rt_trace_any": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
     "rt_trace_closest_device": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP]),
     "rt_trace_any_device": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP]),
+    "rt_trace_closest_device_noalloc": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP]),
     "rt_trace_closest_linear": (C.c_int, [_VP, _VP, C.c_uint64, _VP]),
     "rt_render": (C.c_int, [_VP, C.POINTER(rt_render_params), _VP, _VP]),
     "rt_render_device": (C.c_int, [_VP, C.POINTER(rt_render_params), _VP, _VP, _VP]),
@@ -285,6 +286,9 @@ class Scene:
 
     def trace_closest_device(self, rays_ptr, n, out_ptr, stream=0):
         check(self.lib.rt_trace_closest_device(self.handle, rays_ptr, n, out_ptr, stream))
+
+    def trace_closest_device_noalloc(self, rays_ptr, n, out_ptr, stream=0):
+        check(self.lib.rt_trace_closest_device_noalloc(self.handle, rays_ptr, n, out_ptr, stream))
 
     def trace_any_device(self, rays_ptr, n, out_ptr, stream=0):
         check(self.lib.rt_trace_any_device(self.handle, rays_ptr, n, out_ptr, stream))

@@ -19,14 +19,15 @@
 
 #include "../../include/rays_hip.h"
 #include "bvh_build.h"
+#include "rt_api_internal.h"
 #include "rt_device.h"
 #include "rt_kernels.h"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
-int fail(int code, const char* fmt, ...) {
+int rt_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -36,13 +37,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "%s: %s", #expr, \
-                        hipGetErrorString(e_));                                                \
-    } while (0)
+namespace {
 
 // Owns a set of device allocations; frees them unless released.
 struct DevPool {
@@ -60,13 +55,6 @@ struct DevPool {
     void release() { ptrs.clear(); }
 };
 
-struct TileMap {
-    uint32_t tiles_x = 0, tiles_y = 0;
-    std::vector<uint32_t> list;  // tiles of one shard, ascending
-    uint32_t* d_list = nullptr;
-    std::vector<uint32_t> slot;  // every tile's rank within its shard
-    uint32_t* d_slot = nullptr;
-};
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -82,23 +70,6 @@ inline float g_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a 
 
 }  // namespace
 
-struct rt_ctx {
-    int device = 0;
-    std::mutex mu;
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, TileMap> tile_maps;
-    // Work counters of the persistent kernels: one per launch, taken in turn, so that launches in
-    // flight on different streams do not share one.
-    static constexpr uint32_t N_COUNTERS = 256;
-    uint32_t* d_counters = nullptr;
-    uint32_t next_counter = 0;
-    ~rt_ctx() {
-        if (d_counters) (void)hipFree(d_counters);
-        for (auto& kv : tile_maps) {
-            if (kv.second.d_list) (void)hipFree(kv.second.d_list);
-            if (kv.second.d_slot) (void)hipFree(kv.second.d_slot);
-        }
-    }
-};
 
 // True when the environment variable is set and begins with `c`.
 bool env_is(const char* name, char c) {
@@ -115,56 +86,7 @@ int take_counter(rt_ctx* ctx, hipStream_t stream, uint32_t** out) {
     return RT_OK;
 }
 
-// Per-sample buffers of the camera + shadow pipeline, grown on demand and kept with the scene.
-struct FrameWork {
-    size_t capacity = 0;  // sample slots
-    float4* samp = nullptr;
-    uint32_t* state = nullptr;
-    uint32_t* keys[2] = {nullptr, nullptr};
-    uint32_t* order = nullptr;  // slot numbers in sorted key order (before the sort: ray queues of the levels)
-    uint32_t* counts = nullptr; // rays queued per level of the secondary-ray tree
-    unsigned long long* zbuf = nullptr;  // nearest (t, id) per sample of a frame rendered by projection
-    size_t zbuf_words = 0;
-    bool zbuf_clean = false;             // every word says "none" (the record pass of a whole frame leaves it so)
-    float* cam_table = nullptr;  // image-plane coordinates of the sample columns and rows
-    size_t cam_table_floats = 0;
-    void* temp = nullptr;
-    size_t temp_bytes = 0;
-    void release() {
-        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp})
-            if (q) (void)hipFree(q);
-        *this = FrameWork();
-    }
-};
 
-struct rt_scene {
-    rt_ctx* ctx = nullptr;
-    FrameWork work;         // per sample: camera rays and their shadow rays
-    FrameWork bounce_work;  // per scatter ray of a run of tiles
-    float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
-    // Camera rays by projection (the camera of src/main.rs:314-330 stands at the origin and looks along
-    // +z): possible when no object has trailing triangles and every triangle lies in front of the
-    // camera; raster_dx / raster_dy are the widest extents of a triangle on the image plane z = 1.
-    bool raster_ok = false;
-    float raster_dx = 0.0f, raster_dy = 0.0f;
-    double raster_sum_dx = 0.0, raster_sum_dy = 0.0, raster_sum_area = 0.0;  // over all triangles
-    uint32_t n_tris_total = 0;
-    SceneView view{};
-    std::vector<void*> device_ptrs;
-    uint32_t n_tris = 0;
-    uint32_t n_leaves = 0;
-    uint32_t n_nodes = 0;
-    uint64_t sizes[4] = {0, 0, 0, 0};  // device bytes: wide tree, 4-wide tree, triangle records, tri_data
-    uint32_t max_stack = 0;
-    uint32_t wide_depth = 1;
-    std::vector<DevObject> objects;
-    std::vector<std::vector<uint32_t>> order;  // per object: sorted position -> input position
-    ~rt_scene() {
-        work.release();
-        bounce_work.release();
-        for (void* p : device_ptrs) (void)hipFree(p);
-    }
-};
 
 namespace {
 
@@ -198,18 +120,18 @@ int get_tile_map(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t index, u
 }
 
 int check_render_params(const rt_render_params* p, uint32_t* spp) {
-    if (!p) return fail(RT_ERR_INVALID, "render params are null");
-    if (p->width == 0 || p->height == 0) return fail(RT_ERR_INVALID, "frame size is zero");
-    if ((uint64_t)p->width * p->height > (1ull << 30)) return fail(RT_ERR_INVALID, "frame too large");
+    if (!p) return rt_fail(RT_ERR_INVALID, "render params are null");
+    if (p->width == 0 || p->height == 0) return rt_fail(RT_ERR_INVALID, "frame size is zero");
+    if ((uint64_t)p->width * p->height > (1ull << 30)) return rt_fail(RT_ERR_INVALID, "frame too large");
     if (p->grid != 1 && p->grid != 2 && p->grid != 4 && p->grid != 8)
-        return fail(RT_ERR_UNSUPPORTED, "grid must be 1, 2, 4 or 8 (got %u)", p->grid);
+        return rt_fail(RT_ERR_UNSUPPORTED, "grid must be 1, 2, 4 or 8 (got %u)", p->grid);
     if (p->reflect_depth > RT_MAX_REFLECT + 1)
-        return fail(RT_ERR_UNSUPPORTED, "reflect_depth above %d is not supported", RT_MAX_REFLECT + 1);
-    if (p->diffuse_depth > 2) return fail(RT_ERR_UNSUPPORTED, "diffuse_depth above 2 is not supported");
-    if (p->diffuse_depth > 1 && p->diffuse_scatt == 0) return fail(RT_ERR_INVALID, "diffuse_scatt is zero");
-    if (p->shard_count > 4096) return fail(RT_ERR_UNSUPPORTED, "more than 4096 shards");
+        return rt_fail(RT_ERR_UNSUPPORTED, "reflect_depth above %d is not supported", RT_MAX_REFLECT + 1);
+    if (p->diffuse_depth > 2) return rt_fail(RT_ERR_UNSUPPORTED, "diffuse_depth above 2 is not supported");
+    if (p->diffuse_depth > 1 && p->diffuse_scatt == 0) return rt_fail(RT_ERR_INVALID, "diffuse_scatt is zero");
+    if (p->shard_count > 4096) return rt_fail(RT_ERR_UNSUPPORTED, "more than 4096 shards");
     if (p->shard_count == 0 || p->shard_index >= p->shard_count)
-        return fail(RT_ERR_INVALID, "shard_index %u out of range for shard_count %u", p->shard_index, p->shard_count);
+        return rt_fail(RT_ERR_INVALID, "shard_index %u out of range for shard_count %u", p->shard_index, p->shard_count);
     *spp = p->grid * p->grid;
     return RT_OK;
 }
@@ -217,7 +139,7 @@ int check_render_params(const rt_render_params* p, uint32_t* spp) {
 // Per-sample (or per-ray) arrays of the kernel pipeline, grown on demand and kept with the scene.
 int ensure_work(FrameWork& w, size_t n, hipStream_t stream) {
     if (w.capacity >= n) return RT_OK;
-    if (n >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "too many rays in one launch");
+    if (n >= (1ull << 32)) return rt_fail(RT_ERR_UNSUPPORTED, "too many rays in one launch");
     w.release();
     size_t tb = 0;
     // The temporary size is asked for the widest key, so one workspace serves every key width.
@@ -296,7 +218,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     uint32_t spp = 0;
     int rc = check_render_params(p, &spp);
     if (rc != RT_OK) return rc;
-    if (!d_rgba8) return fail(RT_ERR_INVALID, "rgba8 buffer is null");
+    if (!d_rgba8) return rt_fail(RT_ERR_INVALID, "rgba8 buffer is null");
     DevRenderParams dp{};
     dp.width = p->width;
     dp.height = p->height;
@@ -348,7 +270,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // sorted shadow rays of all levels, and the resolve of everything, over runs of tiles sized so
     // that a run's secondary rays fit the workspace.
     const uint32_t tile_slots = RT_TILE * RT_TILE * spp;
-    if ((size_t)dp.n_tiles * tile_slots >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "frame has too many samples");
+    if ((size_t)dp.n_tiles * tile_slots >= (1ull << 32)) return rt_fail(RT_ERR_UNSUPPORTED, "frame has too many samples");
     if (dp.n_tiles == 0) return RT_OK;
     uint32_t run_tiles = dp.n_tiles;
     RayTree tr{};
@@ -366,7 +288,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const long long v = e ? std::atoll(e) : 0;
         const size_t cap = v > 0 ? (size_t)v : ((size_t)256 << 20);
         const size_t per_tile = (size_t)tile_slots * tr.branches * tr.levels;
-        if (per_tile >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays per tile");
+        if (per_tile >= (1ull << 31)) return rt_fail(RT_ERR_UNSUPPORTED, "too many secondary rays per tile");
         run_tiles = (uint32_t)std::min<size_t>(dp.n_tiles, std::max<size_t>(1, cap / per_tile));
     }
     const size_t run_slots = (size_t)run_tiles * tile_slots;
@@ -495,21 +417,28 @@ const char* rt_last_error(void) { return g_last_error.c_str(); }
 const char* rt_version(void) { return "rays-hip 0.1 (gfx950)"; }
 
 int rt_ctx_create(const int* devices, int n, rt_ctx** out) {
-    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    if (!out) return rt_fail(RT_ERR_INVALID, "out is null");
     *out = nullptr;
-    if (!devices || n != 1) return fail(RT_ERR_INVALID, "exactly one device per context (one process per GPU)");
+    if (!devices || n != 1) return rt_fail(RT_ERR_INVALID, "exactly one device per context (one process per GPU)");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (devices[0] < 0 || devices[0] >= count)
-        return fail(RT_ERR_DEVICE, "device %d not present (%d visible)", devices[0], count);
+        return rt_fail(RT_ERR_DEVICE, "device %d not present (%d visible)", devices[0], count);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, devices[0]));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(RT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", devices[0],
+        return rt_fail(RT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", devices[0],
                     prop.gcnArchName);
+    HIP_TRY(hipSetDevice(devices[0]));
     rt_ctx* c = new (std::nothrow) rt_ctx();
-    if (!c) return fail(RT_ERR_NOMEM, "out of host memory");
+    if (!c) return rt_fail(RT_ERR_NOMEM, "out of host memory");
     c->device = devices[0];
+    // The allocation-free entry point's scratch array: its address on this device, looked up once.
+    const int rc = rt_noalloc_setup(c);
+    if (rc != RT_OK) {
+        delete c;
+        return rc;
+    }
     *out = c;
     return RT_OK;
 }
@@ -525,10 +454,10 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
 }
 
 int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, uint32_t flags, rt_scene** out) {
-    if (!out) return fail(RT_ERR_INVALID, "out is null");
-    if (flags & ~(uint32_t)RT_BUILD_DEVICE) return fail(RT_ERR_INVALID, "unknown build flags %#x", flags);
+    if (!out) return rt_fail(RT_ERR_INVALID, "out is null");
+    if (flags & ~(uint32_t)RT_BUILD_DEVICE) return rt_fail(RT_ERR_INVALID, "unknown build flags %#x", flags);
     *out = nullptr;
-    if (!ctx || !objs || n_objs == 0) return fail(RT_ERR_INVALID, "ctx / objs null or no objects");
+    if (!ctx || !objs || n_objs == 0) return rt_fail(RT_ERR_INVALID, "ctx / objs null or no objects");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
 
@@ -536,20 +465,20 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     uint64_t total_tris = 0, total_verts = 0;
     for (uint32_t o = 0; o < n_objs; ++o) {
         const rt_object_desc& d = objs[o];
-        if (!d.verts || d.n_verts == 0) return fail(RT_ERR_INVALID, "object %u has no vertices", o);
-        if (d.n_tris > 0 && (!d.tris || !d.tri_data)) return fail(RT_ERR_INVALID, "object %u: tris / tri_data null", o);
+        if (!d.verts || d.n_verts == 0) return rt_fail(RT_ERR_INVALID, "object %u has no vertices", o);
+        if (d.n_tris > 0 && (!d.tris || !d.tri_data)) return rt_fail(RT_ERR_INVALID, "object %u: tris / tri_data null", o);
         for (uint64_t i = 0; i < (uint64_t)d.n_tris * 3; ++i)
             if (d.tris[i] >= d.n_verts)
-                return fail(RT_ERR_INVALID, "object %u: vertex index %u out of range (%u vertices)", o, d.tris[i],
+                return rt_fail(RT_ERR_INVALID, "object %u: vertex index %u out of range (%u vertices)", o, d.tris[i],
                             d.n_verts);
         total_tris += d.n_tris;
         total_verts += d.n_verts;
     }
-    if (total_tris >= (1ull << 27)) return fail(RT_ERR_UNSUPPORTED, "more than 2^27 triangles");
-    if (total_verts >= (1ull << 32)) return fail(RT_ERR_UNSUPPORTED, "more than 2^32 vertices");
+    if (total_tris >= (1ull << 27)) return rt_fail(RT_ERR_UNSUPPORTED, "more than 2^27 triangles");
+    if (total_verts >= (1ull << 32)) return rt_fail(RT_ERR_UNSUPPORTED, "more than 2^32 vertices");
 
     rt_scene* s = new (std::nothrow) rt_scene();
-    if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
+    if (!s) return rt_fail(RT_ERR_NOMEM, "out of host memory");
     struct Guard {
         rt_scene* s;
         ~Guard() { delete s; }
@@ -684,9 +613,9 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);
             s->wide_depth = std::max(s->wide_depth, L.depth_wide);
         }
-        if (n_wide_total >= (1u << 26)) return fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+        if (n_wide_total >= (1u << 26)) return rt_fail(RT_ERR_UNSUPPORTED, "wide tree too large");
     }
-    if (s->max_stack > RT_STACK_MAX || s->wide_depth > RT_BEAM_LEVELS) return fail(RT_ERR_UNSUPPORTED, "tree too deep");
+    if (s->max_stack > RT_STACK_MAX || s->wide_depth > RT_BEAM_LEVELS) return rt_fail(RT_ERR_UNSUPPORTED, "tree too deep");
     for (uint32_t o = 0; !device_build && o < n_objs; ++o) {
         DevObject& ob = s->objects[o];
         const uint32_t n_packed = (ob.n_tris / 8) * 8;
@@ -708,9 +637,9 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
         if (res.max_stack > RT_STACK_MAX || res.wide_depth > RT_BEAM_LEVELS)
             rtbvh::build(bounds.data(), n_packed, node_base, rec_base, wide_width, wide_base, nt, true, &res);
         if (res.max_stack > RT_STACK_MAX || res.wide_depth > RT_BEAM_LEVELS)
-            return fail(RT_ERR_UNSUPPORTED, "object %u: tree too deep (%u pending entries, %u wide levels)", o,
+            return rt_fail(RT_ERR_UNSUPPORTED, "object %u: tree too deep (%u pending entries, %u wide levels)", o,
                         res.max_stack, res.wide_depth);
-        if (wide_all.size() + res.wide.size() >= (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+        if (wide_all.size() + res.wide.size() >= (1u << 25)) return rt_fail(RT_ERR_UNSUPPORTED, "wide tree too large");
         ob.wide_root = res.wide_root;
         wide_all.insert(wide_all.end(), res.wide.begin(), res.wide.end());
         s->max_stack = std::max(s->max_stack, res.max_stack);
@@ -873,21 +802,21 @@ void rt_scene_destroy(rt_scene* s) {
 uint32_t rt_scene_num_tris(const rt_scene* s) { return s ? s->n_tris : 0; }
 
 int rt_scene_sizes(const rt_scene* s, uint64_t sizes[4]) {
-    if (!s || !sizes) return fail(RT_ERR_INVALID, "null argument");
+    if (!s || !sizes) return rt_fail(RT_ERR_INVALID, "null argument");
     for (int k = 0; k < 4; ++k) sizes[k] = s->sizes[k];
     return RT_OK;
 }
 
 int rt_scene_order(const rt_scene* s, uint32_t obj, uint32_t* order) {
-    if (!s || !order) return fail(RT_ERR_INVALID, "null argument");
-    if (obj >= s->order.size()) return fail(RT_ERR_INVALID, "object %u out of range", obj);
+    if (!s || !order) return rt_fail(RT_ERR_INVALID, "null argument");
+    if (obj >= s->order.size()) return rt_fail(RT_ERR_INVALID, "object %u out of range", obj);
     if (!s->order[obj].empty()) std::memcpy(order, s->order[obj].data(), s->order[obj].size() * 4);
     return RT_OK;
 }
 
 int rt_scene_packed(const rt_scene* s, uint32_t obj, float* tris9, float* leaf_bounds6) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
-    if (obj >= s->objects.size()) return fail(RT_ERR_INVALID, "object %u out of range", obj);
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (obj >= s->objects.size()) return rt_fail(RT_ERR_INVALID, "object %u out of range", obj);
     HIP_TRY(hipSetDevice(s->ctx->device));
     const DevObject& ob = s->objects[obj];
     if (tris9 && ob.n_tris)
@@ -899,10 +828,10 @@ int rt_scene_packed(const rt_scene* s, uint32_t obj, float* tris9, float* leaf_b
 }
 
 int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, void* stream) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
     if (n == 0) return RT_OK;
-    if (!d_rays || !d_out) return fail(RT_ERR_INVALID, "null buffer");
-    if (n > (1ull << 31) * RT_BLOCK) return fail(RT_ERR_INVALID, "too many rays in one call");
+    if (!d_rays || !d_out) return rt_fail(RT_ERR_INVALID, "null buffer");
+    if (n > (1ull << 31) * RT_BLOCK) return rt_fail(RT_ERR_INVALID, "too many rays in one call");
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     uint32_t* counter = nullptr;
@@ -913,10 +842,10 @@ int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hi
 }
 
 int rt_trace_any_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, uint8_t* d_occluded, void* stream) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
     if (n == 0) return RT_OK;
-    if (!d_rays || !d_occluded) return fail(RT_ERR_INVALID, "null buffer");
-    if (n > (1ull << 31) * RT_BLOCK) return fail(RT_ERR_INVALID, "too many rays in one call");
+    if (!d_rays || !d_occluded) return rt_fail(RT_ERR_INVALID, "null buffer");
+    if (n > (1ull << 31) * RT_BLOCK) return rt_fail(RT_ERR_INVALID, "too many rays in one call");
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     uint32_t* counter = nullptr;
@@ -931,9 +860,9 @@ int rt_trace_any_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, uint8_t* 
 namespace {
 template <class OutT, class Launch>
 int trace_host(rt_scene* s, const rt_ray* rays, uint64_t n, OutT* out, Launch launch) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
     if (n == 0) return RT_OK;
-    if (!rays || !out) return fail(RT_ERR_INVALID, "null buffer");
+    if (!rays || !out) return rt_fail(RT_ERR_INVALID, "null buffer");
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     DevPool tmp;
@@ -984,7 +913,7 @@ uint32_t rt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_index, u
 }
 
 int rt_render_device(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, void* stream) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     return render_common(s, p, d_rgba8, d_hit_ids, nullptr, (hipStream_t)stream);
@@ -992,10 +921,10 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, u
 
 int rt_render_device_events(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, void* stream,
                             void* const* events, int n_events) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
-    if (!events || n_events != RT_RENDER_EVENTS) return fail(RT_ERR_INVALID, "need %d events", RT_RENDER_EVENTS);
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (!events || n_events != RT_RENDER_EVENTS) return rt_fail(RT_ERR_INVALID, "need %d events", RT_RENDER_EVENTS);
     for (int k = 0; k < n_events; ++k)
-        if (!events[k]) return fail(RT_ERR_INVALID, "event %d is null", k);
+        if (!events[k]) return rt_fail(RT_ERR_INVALID, "event %d is null", k);
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     return render_common(s, p, d_rgba8, d_hit_ids, nullptr, (hipStream_t)stream, events);
@@ -1003,7 +932,7 @@ int rt_render_device_events(rt_scene* s, const rt_render_params* p, uint8_t* d_r
 
 int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                            rt_stats* stats) {
-    if (!s || !stats) return fail(RT_ERR_INVALID, "null argument");
+    if (!s || !stats) return rt_fail(RT_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     DevPool tmp;
@@ -1037,11 +966,11 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
 }
 
 int rt_render(rt_scene* s, const rt_render_params* p, uint8_t* rgba8, uint32_t* hit_ids) {
-    if (!s) return fail(RT_ERR_INVALID, "scene is null");
+    if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
     uint32_t spp = 0;
     int rc = check_render_params(p, &spp);
     if (rc != RT_OK) return rc;
-    if (!rgba8) return fail(RT_ERR_INVALID, "rgba8 buffer is null");
+    if (!rgba8) return rt_fail(RT_ERR_INVALID, "rgba8 buffer is null");
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     const size_t n_pix = (size_t)p->width * p->height;
@@ -1086,8 +1015,8 @@ int rt_render(rt_scene* s, const rt_render_params* p, uint8_t* rgba8, uint32_t* 
 
 int rt_deinterleave_tiles_device(rt_ctx* ctx, const uint8_t* d_gathered, uint32_t slab_tiles, uint32_t width,
                                  uint32_t height, uint32_t shard_count, uint8_t* d_rgba8, void* stream) {
-    if (!ctx || !d_gathered || !d_rgba8) return fail(RT_ERR_INVALID, "null argument");
-    if (width == 0 || height == 0 || shard_count == 0) return fail(RT_ERR_INVALID, "bad frame or shard count");
+    if (!ctx || !d_gathered || !d_rgba8) return rt_fail(RT_ERR_INVALID, "null argument");
+    if (width == 0 || height == 0 || shard_count == 0) return rt_fail(RT_ERR_INVALID, "bad frame or shard count");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     TileMap* tm = nullptr;
@@ -1095,7 +1024,7 @@ int rt_deinterleave_tiles_device(rt_ctx* ctx, const uint8_t* d_gathered, uint32_
     if (rc != RT_OK) return rc;
     for (uint32_t sh = 0; sh < shard_count; ++sh)
         if (rt_shard_tiles(width, height, sh, shard_count) > slab_tiles)
-            return fail(RT_ERR_INVALID, "slab_tiles %u is smaller than shard %u's tile count", slab_tiles, sh);
+            return rt_fail(RT_ERR_INVALID, "slab_tiles %u is smaller than shard %u's tile count", slab_tiles, sh);
     HIP_TRY(rtk::deinterleave(d_gathered, tm->d_slot, slab_tiles, width, height, tm->tiles_x,
                               tm->tiles_x * tm->tiles_y, shard_count, d_rgba8, (hipStream_t)stream));
     return RT_OK;

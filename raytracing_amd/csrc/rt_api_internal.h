@@ -1,0 +1,110 @@
+// rt_api_internal.h -- the objects behind the opaque handles of include/rays_hip.h, shared by the
+// translation units that implement its entry points (rt_api.cpp, rt_noalloc.hip).
+#ifndef RT_API_INTERNAL_H
+#define RT_API_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "../../include/rays_hip.h"
+#include "rt_device.h"
+
+// Records the message rt_last_error() returns on the calling thread; returns `code`.
+int rt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return rt_fail(e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "%s: %s", #expr, \
+                           hipGetErrorString(e_));                                                \
+    } while (0)
+
+struct TileMap {
+    uint32_t tiles_x = 0, tiles_y = 0;
+    std::vector<uint32_t> list;  // tiles of one shard, ascending
+    uint32_t* d_list = nullptr;
+    std::vector<uint32_t> slot;  // every tile's rank within its shard
+    uint32_t* d_slot = nullptr;
+};
+
+struct rt_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, TileMap> tile_maps;
+    // Work counters of the persistent kernels: one per launch, taken in turn, so that launches in
+    // flight on different streams do not share one.
+    static constexpr uint32_t N_COUNTERS = 256;
+    uint32_t* d_counters = nullptr;
+    uint32_t next_counter = 0;
+    // This device's copy of the file-scope scratch array of rt_noalloc.hip (its device address).
+    void* noalloc_scratch = nullptr;
+    ~rt_ctx() {
+        if (d_counters) (void)hipFree(d_counters);
+        for (auto& kv : tile_maps) {
+            if (kv.second.d_list) (void)hipFree(kv.second.d_list);
+            if (kv.second.d_slot) (void)hipFree(kv.second.d_slot);
+        }
+    }
+};
+
+// Per-sample buffers of the camera + shadow pipeline, grown on demand and kept with the scene.
+struct FrameWork {
+    size_t capacity = 0;  // sample slots
+    float4* samp = nullptr;
+    uint32_t* state = nullptr;
+    uint32_t* keys[2] = {nullptr, nullptr};
+    uint32_t* order = nullptr;  // slot numbers in sorted key order (before the sort: ray queues of the levels)
+    uint32_t* counts = nullptr; // rays queued per level of the secondary-ray tree
+    unsigned long long* zbuf = nullptr;  // nearest (t, id) per sample of a frame rendered by projection
+    size_t zbuf_words = 0;
+    bool zbuf_clean = false;             // every word says "none" (the record pass of a whole frame leaves it so)
+    float* cam_table = nullptr;  // image-plane coordinates of the sample columns and rows
+    size_t cam_table_floats = 0;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    void release() {
+        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp})
+            if (q) (void)hipFree(q);
+        *this = FrameWork();
+    }
+};
+
+struct rt_scene {
+    rt_ctx* ctx = nullptr;
+    FrameWork work;         // per sample: camera rays and their shadow rays
+    FrameWork bounce_work;  // per scatter ray of a run of tiles
+    float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
+    // Camera rays by projection (the camera of src/main.rs:314-330 stands at the origin and looks along
+    // +z): possible when no object has trailing triangles and every triangle lies in front of the
+    // camera; raster_dx / raster_dy are the widest extents of a triangle on the image plane z = 1.
+    bool raster_ok = false;
+    float raster_dx = 0.0f, raster_dy = 0.0f;
+    double raster_sum_dx = 0.0, raster_sum_dy = 0.0, raster_sum_area = 0.0;  // over all triangles
+    uint32_t n_tris_total = 0;
+    SceneView view{};
+    std::vector<void*> device_ptrs;
+    uint32_t n_tris = 0;
+    uint32_t n_leaves = 0;
+    uint32_t n_nodes = 0;
+    uint64_t sizes[4] = {0, 0, 0, 0};  // device bytes: wide tree, 4-wide tree, triangle records, tri_data
+    uint32_t max_stack = 0;
+    uint32_t wide_depth = 1;
+    std::vector<DevObject> objects;
+    std::vector<std::vector<uint32_t>> order;  // per object: sorted position -> input position
+    ~rt_scene() {
+        work.release();
+        bounce_work.release();
+        for (void* p : device_ptrs) (void)hipFree(p);
+    }
+};
+
+// rt_noalloc.hip: looks up the device address of the file-scope scratch array on the current
+// device (the caller has made ctx->device current) and keeps it in ctx->noalloc_scratch.
+int rt_noalloc_setup(rt_ctx* ctx);
+
+#endif

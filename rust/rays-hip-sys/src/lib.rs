@@ -87,6 +87,9 @@ extern "C" {
     pub fn rt_trace_closest(scene: *mut rt_scene, rays: *const rt_ray, n: u64, out: *mut rt_hit) -> c_int;
     pub fn rt_trace_any(scene: *mut rt_scene, rays: *const rt_ray, n: u64, occluded: *mut u8) -> c_int;
     pub fn rt_trace_closest_device(scene: *mut rt_scene, d_rays: *const rt_ray, n: u64, d_out: *mut rt_hit, stream: *mut c_void) -> c_int;
+    /// `rt_trace_closest_device` without any allocation (work counter in a per-GPU static array);
+    /// at most 2^31 rays per call; overlapping calls on one GPU race.
+    pub fn rt_trace_closest_device_noalloc(scene: *mut rt_scene, d_rays: *const rt_ray, n: u64, d_out: *mut rt_hit, stream: *mut c_void) -> c_int;
     pub fn rt_trace_any_device(scene: *mut rt_scene, d_rays: *const rt_ray, n: u64, d_occluded: *mut u8, stream: *mut c_void) -> c_int;
     pub fn rt_trace_closest_linear(scene: *mut rt_scene, rays: *const rt_ray, n: u64, out: *mut rt_hit) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, p: *const rt_render_params, rgba8: *mut u8, hit_ids: *mut u32) -> c_int;
