@@ -13,7 +13,8 @@
  *    aborts across the boundary. rt_last_error() returns a thread-local message for the last
  *    failure on the calling thread.
  *  - The caller owns every input and output buffer. rt_scene_build copies what it needs; the
- *    library owns device memory until rt_scene_destroy / rt_ctx_destroy.
+ *    library owns device memory until rt_scene_destroy / rt_ctx_destroy. A context destroyed while
+ *    scenes built on it are alive stays valid for them and is freed with the last of them.
  *  - A built scene is immutable. Calls on one rt_ctx are serialised internally.
  *  - Hit id = (sum of the triangle counts of the preceding objects) + index of the triangle in
  *    the object's post-optimize_model order. This is the index the reference uses into

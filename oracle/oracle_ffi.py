@@ -82,6 +82,8 @@ def lib():
         L.rto_triangle_ray_hits.argtypes = [_VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]
         L.rto_calculate_normal.argtypes = [_VP, _VP, _VP, _VP]
         L.rto_calculate_normal.restype = None
+        L.rto_sincos.restype = None
+        L.rto_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rto_rand.restype = C.c_float
         L.rto_rand.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
         _lib = L
@@ -240,3 +242,10 @@ def calculate_normal(a, b, c):
 
 def rand(seed, sample_index, scatter, which):
     return float(lib().rto_rand(seed, sample_index, scatter, which))
+
+
+def sincos(psi):
+    """The injected sine / cosine of the scatter angle, as float32 values."""
+    s, c = C.c_float(), C.c_float()
+    lib().rto_sincos(float(psi), C.byref(s), C.byref(c))
+    return np.float32(s.value), np.float32(c.value)

@@ -501,6 +501,30 @@ inline float counter_rand(uint32_t seed, uint64_t sample_index, uint32_t scatter
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
+// Sine and cosine of the scatter angle psi = rand * 2 * PI (src/main.rs:264-268 take them from libm).
+// Like the random draw, they are injected: one fixed sequence of IEEE operations that the kernels
+// under test repeat bit for bit, because libm differs by an ulp from platform to platform and a
+// direction that differs in its last bit can meet another triangle far away. Quadrant by rounding
+// psi * 2/PI, Cody-Waite reduction with a two-part PI/2, the Cephes single-precision polynomials
+// on [-PI/4, PI/4] (below 2 ulp; checked against double-precision sin / cos in tests/).
+inline void injected_sincos(float psi, float* sin_out, float* cos_out) {
+    const int k = (int)(psi * 0.636619772367581343f + 0.5f);
+    const float kf = (float)k;
+    float r = std::fmaf(-kf, 1.5707962512969970703125f, psi);
+    r = std::fmaf(-kf, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = std::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = std::fmaf(ps, z, -1.6666654611e-1f);
+    const float s = std::fmaf(ps * z, r, r);
+    float pc = std::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = std::fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = std::fmaf(pc * z, z, std::fmaf(-0.5f, z, 1.0f));
+    const int q = k & 3;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sin_out = (q & 2) ? -ss : ss;
+    *cos_out = (q == 1 || q == 2) ? -cc : cc;
+}
+
 // src/main.rs:74-86
 inline void get_tangent_vectors(V3 norm, V3* t1, V3* t2) {
     V3 arbitrary = (std::fabs(norm.z) < 1e-6f) ? v3(0, 0, 1) : v3(1, 0, 0);
@@ -556,8 +580,10 @@ Color trace_ray(const Ray& ray, TraceCtx& cx, uint32_t depth, float* dist) {
             float sin_theta = std::sqrt(counter_rand(cx.p->seed, cx.sample_index, k, 0));
             float cos_theta = std::sqrt(1.0f - sin_theta * sin_theta);
             float psi = counter_rand(cx.p->seed, cx.sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
-            float a = sin_theta * std::cos(psi);
-            float b = sin_theta * std::sin(psi);
+            float sin_psi, cos_psi;
+            injected_sincos(psi, &sin_psi, &cos_psi);
+            float a = sin_theta * cos_psi;
+            float b = sin_theta * sin_psi;
             float c = cos_theta;
             V3 tang1, tang2;
             get_tangent_vectors(h.data.normal, &tang1, &tang2);
@@ -834,6 +860,8 @@ void rto_calculate_normal(const float a[3], const float b[3], const float c[3], 
     out[1] = n.y;
     out[2] = n.z;
 }
+
+void rto_sincos(float psi, float* sin_out, float* cos_out) { injected_sincos(psi, sin_out, cos_out); }
 
 float rto_rand(uint32_t seed, uint64_t sample_index, uint32_t scatter, uint32_t which) {
     return counter_rand(seed, sample_index, scatter, which);

@@ -98,6 +98,8 @@ int  rto_triangle_ray_hits(const float a[3], const float b[3], const float c[3],
 /* calculate_normal (src/objects.rs:5-7). */
 void rto_calculate_normal(const float a[3], const float b[3], const float c[3], float out[3]);
 /* The injected generator: uniform f32 in [0,1) for (seed, sample index, scatter, which). */
+/* The injected sine / cosine of the scatter angle (0 <= psi <= 2 PI), see rays_oracle.cpp. */
+void rto_sincos(float psi, float* sin_out, float* cos_out);
 float rto_rand(uint32_t seed, uint64_t sample_index, uint32_t scatter, uint32_t which);
 
 #ifdef __cplusplus

@@ -445,6 +445,14 @@ int rt_ctx_create(const int* devices, int n, rt_ctx** out) {
 
 void rt_ctx_destroy(rt_ctx* c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (c->live_scenes > 0) {
+            // Scenes hold a pointer to their context: the last rt_scene_destroy deletes it.
+            c->destroy_requested = true;
+            return;
+        }
+    }
     (void)hipSetDevice(c->device);
     delete c;
 }
@@ -789,14 +797,23 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     s->device_ptrs = pool.ptrs;
     pool.release();
     guard.s = nullptr;
+    ctx->live_scenes += 1;
     *out = s;
     return RT_OK;
 }
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
-    (void)hipSetDevice(s->ctx->device);
-    delete s;
+    rt_ctx* c = s->ctx;
+    (void)hipSetDevice(c->device);
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        delete s;
+        c->live_scenes -= 1;
+        last = c->destroy_requested && c->live_scenes == 0;
+    }
+    if (last) delete c;
 }
 
 uint32_t rt_scene_num_tris(const rt_scene* s) { return s ? s->n_tris : 0; }

@@ -1,5 +1,5 @@
 // rt_api_internal.h -- the objects behind the opaque handles of include/rays_hip.h, shared by the
-// translation units that implement its entry points (rt_api.cpp, rt_noalloc.hip).
+// translation units that implement its entry points (rt_api.cpp, rt_noalloc.hip, rt_gather.cpp).
 #ifndef RT_API_INTERNAL_H
 #define RT_API_INTERNAL_H
 
@@ -41,10 +41,18 @@ struct rt_ctx {
     static constexpr uint32_t N_COUNTERS = 256;
     uint32_t* d_counters = nullptr;
     uint32_t next_counter = 0;
+    // Scenes built on this context and not yet destroyed. rt_ctx_destroy on a context that still
+    // has scenes only marks it; the last rt_scene_destroy then deletes it.
+    uint32_t live_scenes = 0;
+    bool destroy_requested = false;
     // This device's copy of the file-scope scratch array of rt_noalloc.hip (its device address).
     void* noalloc_scratch = nullptr;
+    // Slab that rt_gather_tiles_device receives the shards' tiles into (rank 0 only), grown on demand.
+    uint8_t* d_gather = nullptr;
+    size_t gather_bytes = 0;
     ~rt_ctx() {
         if (d_counters) (void)hipFree(d_counters);
+        if (d_gather) (void)hipFree(d_gather);
         for (auto& kv : tile_maps) {
             if (kv.second.d_list) (void)hipFree(kv.second.d_list);
             if (kv.second.d_slot) (void)hipFree(kv.second.d_slot);

@@ -73,6 +73,33 @@ __device__ __forceinline__ bool triangle_ray_hits(rt_f3 va, rt_f3 vb, rt_f3 vc, 
     return false;
 }
 
+// ---- sine and cosine of the scatter angle -----------------------------------------------------
+// The reference takes psi.cos() and psi.sin() of psi = rand * 2 * PI from libm (src/main.rs:264-268).
+// libm results differ by an ulp between hosts and devices, and a scatter direction that differs in
+// its last bit can meet another triangle far away. The random draw itself is injected (the
+// reference's generator is OS-seeded), so the angle's sine and cosine are defined here instead, as
+// one fixed sequence of IEEE operations that the CPU checker repeats bit for bit: quadrant by
+// rounding psi * 2/PI, Cody-Waite reduction with a two-part PI/2, the Cephes single-precision
+// polynomials on [-PI/4, PI/4] (error below 2 ulp of the result), every multiply-add explicit.
+// Valid for 0 <= psi <= 2 PI + a little.
+__device__ __forceinline__ void rt_sincos(float psi, float* sin_out, float* cos_out) {
+    const int k = (int)(psi * 0.636619772367581343f + 0.5f);
+    const float kf = (float)k;
+    float r = __builtin_fmaf(-kf, 1.5707962512969970703125f, psi);   // PI/2, upper 24 bits
+    r = __builtin_fmaf(-kf, 7.54978995489188216e-8f, r);             // PI/2, the rest
+    const float z = r * r;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int q = k & 3;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sin_out = (q & 2) ? -ss : ss;
+    *cos_out = (q == 1 || q == 2) ? -cc : cc;
+}
+
 // ---- the 8-wide kernels, one lane of them ----------------------------------------------------
 // avx_multi_cross, src/simd_accel.rs:136-142: fmsub(a1,b2, b1*a2) etc.
 __device__ __forceinline__ rt_f3 s_cross(rt_f3 a, rt_f3 b) {

@@ -1537,8 +1537,10 @@ __device__ __forceinline__ rt_f3 diffuse_dir(uint32_t seed, uint64_t sample_inde
     const float sin_theta = __builtin_sqrtf(counter_rand(seed, sample_index, k, 0));
     const float cos_theta = __builtin_sqrtf(1.0f - sin_theta * sin_theta);
     const float psi = counter_rand(seed, sample_index, k, 1) * 2.0f * 3.14159265358979323846f;
-    const float a = sin_theta * cosf(psi);
-    const float b = sin_theta * sinf(psi);
+    float sin_psi, cos_psi;
+    rt_sincos(psi, &sin_psi, &cos_psi);
+    const float a = sin_theta * cos_psi;
+    const float b = sin_theta * sin_psi;
     const float c = cos_theta;
     return g_normalize(f3(a * tang1.x + b * tang2.x + c * normal.x, a * tang1.y + b * tang2.y + c * normal.y,
                           a * tang1.z + b * tang2.z + c * normal.z));
@@ -2420,10 +2422,8 @@ hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, 
     if (n == 0) return hipSuccess;
     // RAYS_HIP_TRACE = lane: one ray per lane to the end; wave: wave-coherent walks; default: the
     // persistent per-lane walk.
-    static const int walk = [] {
-        const char* e = std::getenv("RAYS_HIP_TRACE");
-        return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'w' ? 2 : 0));
-    }();
+    const char* e = std::getenv("RAYS_HIP_TRACE");
+    const int walk = !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'w' ? 2 : 0));
     if (walk == 0 && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
         hipLaunchKernelGGL(k_trace_closest_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_out);
@@ -2438,10 +2438,8 @@ hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, 
 hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, uint32_t* d_counter,
                      hipStream_t s) {
     if (n == 0) return hipSuccess;
-    static const bool lane_walk = [] {
-        const char* e = std::getenv("RAYS_HIP_TRACE");
-        return e && e[0] == 'l';
-    }();
+    const char* e = std::getenv("RAYS_HIP_TRACE");
+    const bool lane_walk = e && e[0] == 'l';
     if (!lane_walk && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
         hipLaunchKernelGGL(k_trace_any_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_occ);

@@ -2,8 +2,9 @@
 
 Bar: hit ids bit-exact except at documented rounding-edge rays, whose share must stay below
 1e-5 (the north-star figure: agreement >= 99.999 %); t, u, v bit-exact wherever the ids agree
-(the kernels repeat the reference's operation sequence); colours within 1 LSB of 8 bits (libm's
-powf / sinf / cosf differ between host and device by ulps).
+(the kernels repeat the reference's operation sequence); colours within 1 LSB of 8 bits (the gamma
+curve's powf differs between host and device by ulps; the scatter directions do not: generator,
+sine and cosine are injected on both sides).
 """
 import numpy as np
 import pytest
@@ -106,11 +107,11 @@ def test_incoherent_rays_closest_and_any(which, teapot_pair, soup_pair):
     rays = _secondary_rays(ref_p, prim, rng, 40000)
     ref = o.trace_closest(rays)
     gpu = g.trace_closest(rays)
-    _compare_hits(gpu, ref, 1e-4)
+    _compare_hits(gpu, ref, 1e-5)
     occ_ref = o.trace_any(rays)
     occ_gpu = g.trace_any(rays)
     diff = (occ_ref != occ_gpu).mean()
-    assert diff <= 1e-4, f"any-hit differs on {diff:.2e} of rays"
+    assert diff <= 1e-5, f"any-hit differs on {diff:.2e} of rays"
     assert 0.05 < occ_ref.mean() < 1.0
 
 
@@ -192,10 +193,10 @@ def test_render_default_scene_full_recursion(teapot_pair):
     assert 1.0 - same.mean() <= 1e-5
     ok = same.reshape(-1, 4).all(axis=1).reshape(H, W)
     d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16))[ok]
-    # Secondary rays start from computed hit points, so a 1-ulp libm difference can flip a far
-    # bounce; allow a thin tail beyond 1 LSB and bound it.
-    assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
-    print(f"full recursion: max diff {d.max()}, share > 1 LSB {(d > 1).mean():.2e}")
+    # Scatter directions are bit-identical on both sides (injected generator, injected sine and
+    # cosine), so every secondary ray is the same ray; what is left is the gamma curve's rounding.
+    assert d.max() <= 1, f"{(d > 1).sum()} channels differ by more than 1 LSB (max {d.max()})"
+    print(f"full recursion: max diff {d.max()}, exact on {(d == 0).mean():.4f} of channels")
 
 
 @pytest.mark.parametrize("reflect_depth", [1, 2, 4, 9])
@@ -245,9 +246,7 @@ def test_render_soup_diffuse_bounce_pipeline(soup_pair, monkeypatch):
     assert 1.0 - same.mean() <= 1e-5
     ok = same.reshape(-1, 4).all(axis=1).reshape(ref_rgba.shape[:2])
     d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16))[ok]
-    # Scatter rays start from computed hit points and use sin/cos: a 1-ulp libm difference can flip
-    # a far bounce; allow a thin tail beyond 1 LSB and bound it.
-    assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
+    assert d.max() <= 1, f"{(d > 1).sum()} channels differ by more than 1 LSB (max {d.max()})"
     monkeypatch.setenv("RAYS_HIP_BOUNCE_RAYS", str(3 * 1024 * 4 * 10))   # three tiles per run
     rgba_runs, ids_runs = g.render(p, want_hit_ids=True)
     assert np.array_equal(rgba_runs, rgba) and np.array_equal(ids_runs, ids)
@@ -303,7 +302,7 @@ def test_render_soup_diffuse_pipeline_with_the_sun_aside(soup_pair):
     assert 1.0 - same.mean() <= 1e-5
     ok = same.reshape(-1, 4).all(axis=1).reshape(ref_rgba.shape[:2])
     d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16))[ok]
-    assert (d > 1).mean() <= 2e-4, f"{(d > 1).sum()} channels differ by more than 1 LSB"
+    assert d.max() <= 1, f"{(d > 1).sum()} channels differ by more than 1 LSB (max {d.max()})"
 
 
 def test_tree_pipeline_with_a_mirror_no_ray_reaches(ctx, soup64k, monkeypatch):
@@ -456,7 +455,7 @@ def test_golden_vectors(name, ctx, default_objects):
     assert np.abs(rgba.astype(np.int16) - gold[f"{name}_frame_direct"].astype(np.int16)).max() <= 1
     rgba = g.render(render_params(64, 36, 2, seed=99))
     d = np.abs(rgba.astype(np.int16) - gold[f"{name}_frame_full"].astype(np.int16))
-    assert (d > 1).mean() <= 1e-3
+    assert d.max() <= 1, f"{(d > 1).sum()} channels of the full-recursion frame differ by more than 1 LSB"
 
 
 def test_deinterleave_kernel_matches_numpy(ctx):
@@ -574,38 +573,11 @@ def test_device_built_tree_gives_the_same_answers(which, ctx, oracle, default_ob
     org = rng.uniform(-8, 8, (n, 3)).astype(np.float32) + np.array([0, 0, 12], dtype=np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
     inc = np.concatenate([org, d], axis=1)
-    _compare_hits(g.trace_closest(inc), o.trace_closest(inc), 1e-4)
-    assert (g.trace_any(inc) != o.trace_any(inc)).mean() <= 1e-4
+    _compare_hits(g.trace_closest(inc), o.trace_closest(inc), 1e-5)
+    assert (g.trace_any(inc) != o.trace_any(inc)).mean() <= 1e-5
     W, H = 200, 120
     kw = dict(reflect_depth=1, diffuse_depth=1)
     ref_rgba, ref_ids, _ = o.render(W, H, 2, want_hit_ids=True, **kw)
     rgba, ids = g.render(render_params(W, H, 2, **kw), want_hit_ids=True)
     _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
     g.close()
-
-
-def test_full_size_properties_soup_1m(ctx, oracle):
-    """The benchmark workload at full size: 1,000,000 triangles, 3840x2160, four samples. The
-    oracle cannot scan it in full in test time, so: a strided subsample is compared ray by ray, the
-    frame is deterministic across runs, and the hit-id buffer is consistent with the frame."""
-    objs = scenes.soup(1_000_000, 0x5EED0001)
-    g = Scene(ctx, objs)
-    W, H = 3840, 2160
-    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1)
-    rgba, ids = g.render(p, want_hit_ids=True)
-    rgba2 = g.render(p)
-    assert np.array_equal(rgba, rgba2), "frame is not deterministic"
-    assert (rgba[..., 3] == 255).all()
-    hit = ids != RT_MISS
-    assert 0.5 < hit.mean() < 1.0 and ids[hit].max() < 1_000_000
-    # pixels whose four samples all miss are exactly the sky colour
-    sky = ~hit.reshape(-1, 4).any(axis=1)
-    assert sky.any() and (rgba.reshape(-1, 4)[sky] == np.array([0x87, 0xCE, 0xEB, 0xFF], dtype=np.uint8)).all()
-    # strided subsample against the oracle (every 4099th pixel: 2,023 pixels, 8,092 rays)
-    pix = np.arange(0, W * H, 4099)
-    rays = scenes.camera_rays(W, H, 2, pixels=pix)
-    ref = oracle.OracleScene(objs).trace_closest(rays)
-    sub = ids.reshape(-1, 4)[pix].reshape(-1)
-    assert (sub != ref["tri"]).mean() <= 1e-3
-    batch = g.trace_closest(rays)
-    _compare_hits(batch, ref, 1e-3)

@@ -230,3 +230,18 @@ def test_counter_rng_is_uniform_and_keyed(oracle):
     assert v.min() >= 0.0 and v.max() < 1.0 and abs(v.mean() - 0.5) < 0.03
     assert oracle.rand(7, 1, 0, 0) != oracle.rand(8, 1, 0, 0) != oracle.rand(7, 1, 0, 1)
     assert oracle.rand(7, 1, 0, 0) == oracle.rand(7, 1, 0, 0)
+
+
+def test_injected_sincos_is_accurate_and_exact_at_the_axes(oracle):
+    """The sine / cosine of the scatter angle that oracle and kernels share in place of libm
+    (src/main.rs:264-268): within 1.2e-7 of the true values over the draws the generator can make,
+    on the unit circle, exact at psi = 0."""
+    assert oracle.sincos(0.0) == (np.float32(0.0), np.float32(1.0))
+    worst = 0.0
+    for k in range(0, 1 << 24, 4099):
+        u = np.float32(k) * np.float32(1.0 / 16777216.0)
+        psi = np.float32(np.float32(u * np.float32(2.0)) * np.float32(3.14159265358979323846))
+        s, c = oracle.sincos(psi)
+        worst = max(worst, abs(float(s) - np.sin(float(psi))), abs(float(c) - np.cos(float(psi))))
+        assert abs(float(s) ** 2 + float(c) ** 2 - 1.0) < 4e-7
+    assert worst < 1.2e-7
