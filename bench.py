@@ -5,13 +5,20 @@ Workload (the configuration the headline metric is quoted on): the synthetic
 1,000,000-triangle soup (PCG32 seed 0x5EED0001), one 3840x2160 frame at four samples per pixel:
 camera rays generated on the device, nearest-hit search, one sun shadow ray per lit hit, shading,
 sub-sample average, RGBA8. One step = one frame. Mrays/s counts nearest-hit plus shadow searches.
+In this configuration the library finds the camera rays' nearest hits by projecting the triangles
+onto the sample grid (same results as the tree walk); `value` is that default path and
+`value_tree_walk` the same frame with every ray walked through the tree (RAYS_HIP_RASTER=0).
+A short run of the diffuse-bounce workload (soup-10M, config 4) adds a roofline entry for the
+kernel that traces the incoherent secondary rays.
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the same frame is split into 32x32-pixel tiles dealt out diagonally to the ranks
 (every rank holds the whole scene) and rank 0 collects the tiles with one RCCL gather per frame,
-overlapped with the next frame's rendering ("scaling": "strong").
+overlapped with the next frame's rendering ("scaling": "strong"). The gather is the library's own
+rt_gather_tiles_device (grouped ncclSend / ncclRecv into rank 0 + tile scatter) on a communicator
+made by rt_comm_create.
 """
 import argparse
 import json
@@ -57,7 +64,77 @@ def cpu_baseline(objects, width, height, target_seconds=20.0):
         "cores": cores,
         "kind": "port",
         "sample": f"every {stride}th pixel of the {width}x{height} frame, 4 samples each: {rays} rays "
-                  f"(nearest-hit + shadow) in {dt:.1f} s; C++ restatement of the reference's AVX2 linear scan",
+                  f"(nearest-hit + shadow) in {dt:.1f} s; C++ restatement of the reference's AVX2 linear scan, "
+                  f"built with g++ -O3 -mavx2 -mfma -ffp-contract=off (not -march=native: it is built on "
+                  f"one machine and run on another), {cores} threads over image rows",
+    }
+
+
+def bounce_roofline(ctx, args, new_event, elapsed_ms):
+    """A short run of the diffuse-bounce workload (config 4: soup-10M, 3840x2160, four samples, ten
+    scatter rays off every hit and the shadow rays of all of them): frame time, and the roofline
+    of k_wf_bounce, the persistent per-lane walk that traces the scatter rays. One launch = one level
+    of a frame's secondary rays; this scene has no mirrors, so one launch per frame."""
+    import torch
+
+    from raytracing_amd import Scene, render_params, scenes
+
+    W, H = args.width, args.height
+    # One run of tiles for the whole frame (the default workspace limit would cut this frame in two, and
+    # the events around the bounce launches cover one run).
+    os.environ.setdefault("RAYS_HIP_BOUNCE_RAYS", str(W * H * 4 * 10 + 1))
+    objects = scenes.soup(args.bounce_tris, 0x5EED0002)
+    scene = Scene(ctx, objects)
+    del objects
+    p = render_params(W, H, 2, reflect_depth=4, diffuse_depth=2, diffuse_scatt=10, sun=scenes.SUN_T0, seed=1)
+    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    sh = torch.cuda.current_stream().cuda_stream
+    st = scene.render_device_stats(p, frame.data_ptr())     # instrumented build: counters of the bounce launches
+    scene.render_device(p, frame.data_ptr(), None, sh)
+    torch.cuda.synchronize()
+    n = 3
+    events = [[new_event() for _ in range(7)] for _ in range(n)]
+    t0 = time.perf_counter()
+    for i in range(n):
+        scene.render_device_events(p, frame.data_ptr(), [e.value for e in events[i]], None, sh)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    bounce_ms = float(np.mean([elapsed_ms(ev[5], ev[6]) for ev in events]))
+    sizes = scene.sizes()
+    scene.close()
+    # Unit = one scatter ray; one launch = the scatter rays of one frame (st["bounce_rays"] of them,
+    # out of samples * 10 ray slots: samples that hit nothing cast none). Algorithmic bytes of a
+    # launch: per slot a 24-byte record out (hit point + id 16, state 4, sort key 4), per sample
+    # its 20-byte record in, plus the 4-wide tree, the triangle records and the normals / colours once.
+    samples = st["primary_rays"]
+    slots = samples * 10
+    alg_bytes = 24 * slots + 20 * samples + sizes["nodes4"] + sizes["recs"] + sizes["tri_data"]
+    flops = FLOP_BOX * st["bounce_box_tests"] + FLOP_TRI * st["bounce_tri_tests"]
+    sec = bounce_ms * 1e-3
+    return {
+        "workload": f"soup-{args.bounce_tris} seed 0x5eed0002, {W}x{H}, 4 samples/pixel, 10 scatter rays per hit + shadow rays",
+        "frame_ms": dt * 1e3,
+        "rays_per_frame": st["rays"],
+        "mrays_per_s": st["rays"] / dt / 1e6,
+        "bound": "hbm",
+        "kernel": "k_wf_bounce",
+        "kernel_ms": bounce_ms,
+        "scatter_rays": st["bounce_rays"],
+        "scatter_mrays_per_s": st["bounce_rays"] / sec / 1e6,
+        "box_tests_per_ray": st["bounce_box_tests"] / max(1, st["bounce_rays"]),
+        "tri_tests_per_ray": st["bounce_tri_tests"] / max(1, st["bounce_rays"]),
+        "achieved": alg_bytes / sec / 1e9,
+        "peak": HBM_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": alg_bytes / sec / HBM_PEAK,
+        "traffic": None,
+        "alg_bytes_per_launch": alg_bytes,
+        "alg_bytes_parts": {"samples": samples, "ray_slots": slots, "nodes4": sizes["nodes4"], "recs": sizes["recs"],
+                            "tri_data": sizes["tri_data"]},
+        "requested_bytes_per_launch": st["bounce_fetch_bytes"],
+        "requested_tb_per_s": st["bounce_fetch_bytes"] / sec / 1e12,
+        "valu_tflops": flops / sec / 1e12,
+        "valu_frac": flops / sec / FP32_PEAK,
     }
 
 
@@ -71,12 +148,14 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tree-walk and diffuse-bounce legs")
+    ap.add_argument("--bounce-tris", type=int, default=10_000_000)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    from raytracing_amd import Context, Scene, render_params, scenes
+    from raytracing_amd import Comm, Context, Scene, comm_id_create, render_params, scenes
     from raytracing_amd import distributed as rd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,6 +183,15 @@ def main():
     t0 = time.perf_counter()
     scene = Scene(ctx, objects)
     build_s = time.perf_counter() - t0
+    # The library's own RCCL communicator for the per-frame gather: rank 0 makes the id, the others
+    # get it over the process group, every rank joins.
+    comm = None
+    ranks_seen = 1
+    if world > 1 and backend == "nccl":
+        box = [comm_id_create() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = Comm(ctx, box[0], rank, world)
+        ranks_seen = comm.ranks()[1]
 
     p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0,
                       shard_index=rank, shard_count=world)
@@ -146,7 +234,7 @@ def main():
         assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
         return ms.value
 
-    phase_events = [[new_event() for _ in range(5)] for _ in range(args.steps)]
+    phase_events = [[new_event() for _ in range(7)] for _ in range(args.steps)]
 
     def step(i, timed_index=None):
         b = i % 2
@@ -165,15 +253,16 @@ def main():
         render_done[b].record(stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(render_done[b])
-            if backend == "nccl":
-                gathered, _ = rd.gather_slabs(frames[b], slab_bytes, dst=0)
+            if comm is not None:
+                comm.gather_tiles_device(frames[b].data_ptr(), W, H, full.data_ptr() if rank == 0 else None,
+                                         comm_stream.cuda_stream)
             else:
                 host, _ = rd.gather_slabs(frames[b].cpu(), slab_bytes, dst=0)
-                gathered = host.to(dev) if rank == 0 else None
-            if rank == 0:
-                ctx.deinterleave_device(gathered.data_ptr(), slab, W, H, world, full.data_ptr(),
-                                        comm_stream.cuda_stream)
-                gathered.record_stream(comm_stream)
+                if rank == 0:
+                    gathered = host.to(dev)
+                    ctx.deinterleave_device(gathered.data_ptr(), slab, W, H, world, full.data_ptr(),
+                                            comm_stream.cuda_stream)
+                    gathered.record_stream(comm_stream)
             gather_done[b].record(comm_stream)
 
     def fence():
@@ -194,6 +283,32 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # The same frame with every camera ray walked through the tree (no projection), timed the same
+    # way: K steps between fences. Single GPU only, after the headline run.
+    tree_walk = None
+    if world == 1 and not args.no_extras:
+        os.environ["RAYS_HIP_RASTER"] = "0"
+        st_walk = scene.render_device_stats(p, frames[0].data_ptr())
+        walk_events = [[new_event() for _ in range(7)] for _ in range(args.steps)]
+        for i in range(args.warmup):
+            scene.render_device(p, frames[0].data_ptr(), None, sh)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            scene.render_device_events(p, frames[0].data_ptr(), [e.value for e in walk_events[i]], None, sh)
+        fence()
+        dt_walk = time.perf_counter() - t0
+        del os.environ["RAYS_HIP_RASTER"]
+        walk_ms = [float(np.mean([elapsed_ms(ev[k], ev[k + 1]) for ev in walk_events])) for k in range(4)]
+        tree_walk = {
+            "value": st_walk["rays"] * args.steps / dt_walk / 1e6,
+            "ms_per_step": dt_walk / args.steps * 1e3,
+            "phase_ms": {"camera_rays": walk_ms[0], "shadow_sort": walk_ms[1], "shadow_rays": walk_ms[2], "resolve": walk_ms[3]},
+            "box_tests_per_ray": st_walk["box_tests"] / max(1, st_walk["rays"]),
+            "tri_tests_per_ray": st_walk["tri_tests"] / max(1, st_walk["rays"]),
+            "valu_frac": (FLOP_BOX * st_walk["box_tests"] + FLOP_TRI * st_walk["tri_tests"]) * args.steps / dt_walk / FP32_PEAK,
+        }
+
     # Self-check of the sharded path (not timed): the frame rank 0 assembled from the ranks' tiles
     # must equal the same frame rendered whole on rank 0's GPU.
     frame_ok = None
@@ -237,18 +352,13 @@ def main():
             my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
         alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
-        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (collected with
-        # rocprofv3, not live): only quoted for the workload it was measured on.
+        # HBM traffic needs hardware counters (rocprofv3 --pmc passes of this very command): not
+        # measured inside this process. The kept summaries are under profiles/.
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pm = json.load(f)
-            if world == 1 and (args.tris, args.seed, W, H) == (1_000_000, 0x5EED0001, 3840, 2160):
-                traffic = pm[kernel]["bytes_per_launch"]
-        except (OSError, KeyError):
-            pass
         out = {
-            "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays)",
+            "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays; camera rays' nearest hits by "
+                      "projection of the triangles onto the sample grid, shadow rays by tree walk; "
+                      "value_tree_walk = every ray by tree walk)",
             "value": value,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -273,6 +383,9 @@ def main():
                 "parallelism": f"tiles{world}" if world > 1 else "single",
                 "sharded_frame_equals_whole_frame": frame_ok,
                 "backend": backend if world > 1 else None,
+                "gather": ("rt_gather_tiles_device (RCCL send/recv to rank 0)" if comm is not None else
+                           ("host-staged rehearsal" if world > 1 else None)),
+                "ranks_seen": ranks_seen,
             },
             "roofline": {
                 "bound": "hbm",
@@ -282,6 +395,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "traffic": traffic,
+                "traffic_profile": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)",
                 "kernel_ms": kernel_ms,
                 "alg_bytes_per_launch": alg_bytes,
                 "requested_bytes_per_launch": requested_bytes,
@@ -290,11 +404,21 @@ def main():
                 "valu_frac": alg_flops / (kernel_ms * 1e-3) / FP32_PEAK,
             },
         }
+        if tree_walk is not None:
+            out["value_tree_walk"] = tree_walk["value"]
+            out["ms_per_step_tree_walk"] = tree_walk["ms_per_step"]
+            out["tree_walk"] = tree_walk
+        if world == 1 and not args.no_extras:
+            # Free the headline scene's frame workspace before the 10M-triangle scene comes in.
+            scene.close()
+            out["roofline_bounce"] = bounce_roofline(ctx, args, new_event, elapsed_ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objects, W, H)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
 
+    if comm is not None:
+        comm.close()
     scene.close()
     ctx.close()
     if world > 1:

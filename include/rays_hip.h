@@ -96,10 +96,13 @@ typedef struct {
                                       sample grid; the primary_* counters then count samples put
                                       through the triangle test (tri), object box tests (box) and
                                       blocks of 8 x 8 samples stepped over (node)                  */
+    /* The launches that trace the secondary rays of a frame with diffuse scattering (scatter and
+     * mirror rays, every level; their shadow rays are not among them): zero for other frames.   */
+    uint64_t bounce_rays, bounce_box_tests, bounce_tri_tests, bounce_node_visits, bounce_fetch_bytes;
 } rt_stats;
 
 /* Number of events rt_render_device_events records. */
-#define RT_RENDER_EVENTS 5
+#define RT_RENDER_EVENTS 7
 
 #define RT_TILE 32u   /* screen tiles are RT_TILE x RT_TILE pixels                           */
 
@@ -181,7 +184,10 @@ int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint
 /* As rt_render_device, and records the caller's hipEvent_t handles on the stream around the
  * frame's phases: events[0] before the camera-ray kernel, [1] after it, [2] after the shadow-ray
  * sort, [3] after the shadow-ray kernel, [4] after the resolve kernel. A frame that runs as one
- * kernel records [0] before and [1]..[4] after it. For measurement; no reference counterpart. */
+ * kernel records [0] before and [1]..[4] after it. Frames with diffuse scattering also record [5]
+ * before and [6] after the launches that trace the secondary rays (all levels of the frame's last
+ * run of tiles; [3] then follows the shadow rays of those levels); other frames record [5] and
+ * [6] together with [4]. For measurement; no reference counterpart. */
 int  rt_render_device_events(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                              void* stream, void* const* events, int n_events);
 /* As rt_render_device, from an instrumented build of the same kernels; synchronises and fills
@@ -197,6 +203,31 @@ uint32_t rt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_index,
 int  rt_deinterleave_tiles_device(rt_ctx*, const uint8_t* d_gathered, uint32_t slab_tiles,
                                   uint32_t width, uint32_t height, uint32_t shard_count,
                                   uint8_t* d_rgba8, void* stream);
+
+/* ---- several GPUs ----------------------------------------------------------------------- */
+/* One process per GPU; every process builds the same scene and renders its shard of the frame
+ * (rt_render_params.shard_index / shard_count = its rank and the number of ranks) into a compact
+ * slab of its tiles; one exchange step per frame brings the slabs to rank 0. No reference
+ * counterpart: the reference renders on one host (src/main.rs:313-379).
+ *
+ * rt_gather_tiles_device is that step. nccl_comm is an RCCL communicator (ncclComm_t) over the
+ * ranks, made by the host's own RCCL binding or by rt_comm_create; rank and rank count are read
+ * from it. Every rank passes its slab (the d_rgba8 of its rt_render_device call: rt_shard_tiles()
+ * tiles of RT_TILE * RT_TILE * 4 bytes); ranks other than 0 enqueue one ncclSend of it and ignore
+ * d_rgba8; rank 0 enqueues its own copy, one ncclRecv per peer (grouped) and the scatter of all
+ * tiles into d_rgba8 = width * height * 4 bytes. Everything is enqueued on `stream`; nothing
+ * synchronises (except once when rank 0's receive slab grows). */
+int  rt_gather_tiles_device(rt_ctx*, void* nccl_comm, const uint8_t* d_slab, uint32_t width,
+                            uint32_t height, uint8_t* d_rgba8, void* stream);
+/* Communicator helpers for hosts without an RCCL binding of their own: rank 0 calls
+ * rt_comm_id_create and hands the 128 bytes to the other ranks over any host channel; then every
+ * rank calls rt_comm_create (collective: ncclCommInitRank on the context's GPU). */
+#define RT_COMM_ID_BYTES 128
+typedef struct { char bytes[RT_COMM_ID_BYTES]; } rt_comm_id;
+int  rt_comm_id_create(rt_comm_id* out);
+int  rt_comm_create(rt_ctx*, const rt_comm_id*, int rank, int n_ranks, void** nccl_comm);
+int  rt_comm_ranks(void* nccl_comm, int* rank, int* n_ranks);
+int  rt_comm_destroy(void* nccl_comm);
 
 /* ---- misc ------------------------------------------------------------------------------ */
 const char* rt_last_error(void);

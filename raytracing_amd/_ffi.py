@@ -66,6 +66,11 @@ class rt_stats(C.Structure):
         ("fetch_bytes", C.c_uint64),
         ("primary_fetch_bytes", C.c_uint64),
         ("camera_by_projection", C.c_uint64),
+        ("bounce_rays", C.c_uint64),
+        ("bounce_box_tests", C.c_uint64),
+        ("bounce_tri_tests", C.c_uint64),
+        ("bounce_node_visits", C.c_uint64),
+        ("bounce_fetch_bytes", C.c_uint64),
     ]
 
 
@@ -99,6 +104,11 @@ SYMBOLS = {
         C.c_int,
         [_VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP, _VP],
     ),
+    "rt_gather_tiles_device": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP]),
+    "rt_comm_id_create": (C.c_int, [_VP]),
+    "rt_comm_create": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "rt_comm_ranks": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rt_comm_destroy": (C.c_int, [_VP]),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
 }
@@ -208,6 +218,40 @@ class Context:
     def deinterleave_device(self, gathered_ptr, slab_tiles, width, height, shard_count, rgba_ptr, stream=0):
         check(self.lib.rt_deinterleave_tiles_device(self.handle, gathered_ptr, slab_tiles, width, height,
                                                     shard_count, rgba_ptr, stream))
+
+
+RT_COMM_ID_BYTES = 128
+
+
+def comm_id_create():
+    """rt_comm_id_create: the 128 bytes rank 0 hands to the other ranks."""
+    buf = C.create_string_buffer(RT_COMM_ID_BYTES)
+    check(hip_lib().rt_comm_id_create(buf))
+    return buf.raw
+
+
+class Comm:
+    """An RCCL communicator over the ranks of one node, made by rt_comm_create (collective)."""
+
+    def __init__(self, ctx, comm_id, rank, n_ranks):
+        self.lib = ctx.lib
+        self.ctx = ctx
+        self.handle = _VP()
+        buf = C.create_string_buffer(bytes(comm_id), RT_COMM_ID_BYTES)
+        check(self.lib.rt_comm_create(ctx.handle, buf, rank, n_ranks, C.byref(self.handle)))
+
+    def ranks(self):
+        r, n = C.c_int(), C.c_int()
+        check(self.lib.rt_comm_ranks(self.handle, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def gather_tiles_device(self, slab_ptr, width, height, rgba_ptr, stream=0):
+        check(self.lib.rt_gather_tiles_device(self.ctx.handle, self.handle, slab_ptr, width, height, rgba_ptr, stream))
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_comm_destroy(self.handle)
+            self.handle = _VP()
 
 
 class Scene:

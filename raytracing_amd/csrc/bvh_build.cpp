@@ -15,7 +15,15 @@ namespace rtbvh {
 namespace {
 
 constexpr int BINS = 16;
-constexpr float PAD_REL = 6e-6f;  // relative widening of every triangle box, per axis
+// Every triangle box is widened per axis by PAD_REL of its own largest coordinate plus PAD_ABS of
+// the object's largest coordinate. The walks' slab tests and the reference's triangle test both
+// round with errors proportional to the coordinates involved (origin, box planes, hit point), so
+// for rays that start within about the object's own size of it -- camera rays from the origin,
+// shadow and bounce rays from hit points -- the padded box is reached whenever the triangle test
+// could accept; for origins much farther away than that the rounding of origin * 1 / direction
+// grows with the origin and a grazing hit at a box edge can be missed (a documented edge class).
+constexpr float PAD_REL = 6e-6f;
+constexpr float PAD_ABS = 1e-6f;
 
 // Tuning knobs (environment, read once): largest leaf and the price of one traversal step in
 // triangle tests.
@@ -387,7 +395,7 @@ struct Collapser {
             ch.ref = c.count > 0 ? leaf_ref[kids[i]] : emit_wide(kids[i], width, wide_base, depth + 1);
             out.wide[first + i] = ch;
         }
-        return ((wide_base + first) << 6) | (uint32_t)(kids.size() - 1);
+        return wide_ref(wide_base + first, (uint32_t)kids.size());
     }
 
     static float half_area(const Node2& n) {
@@ -482,12 +490,15 @@ void build(const float* tri_bounds, uint32_t n, uint32_t node_index_base, uint32
     if (n == 0) return;
     wide_width = std::min(std::max(wide_width, 2u), MAX_WIDE);
     std::vector<Prim> prims(n);
+    float largest = 0.0f;
+    for (size_t i = 0; i < 6 * (size_t)n; ++i) largest = std::max(largest, std::fabs(tri_bounds[i]));
+    const float abs_pad = largest * PAD_ABS + 1e-30f;
     for (uint32_t i = 0; i < n; ++i) {
         const float* b = tri_bounds + 6 * (size_t)i;
         Prim& p = prims[i];
         for (int k = 0; k < 3; ++k) {
             float lo = b[k], hi = b[3 + k];
-            float pad = std::max(std::fabs(lo), std::fabs(hi)) * PAD_REL + 1e-30f;
+            float pad = std::max(std::fabs(lo), std::fabs(hi)) * PAD_REL + abs_pad;
             p.lo[k] = lo - pad;
             p.hi[k] = hi + pad;
             p.c[k] = 0.5f * lo + 0.5f * hi;

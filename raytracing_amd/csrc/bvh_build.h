@@ -35,6 +35,12 @@ constexpr uint32_t MAX_LEAF = 4;
 // (index of the first child << 6) | (count - 1); leaf references are those of the 4-wide tree
 // and point at the same triangle records.
 constexpr uint32_t MAX_WIDE = 64;
+// An inner reference keeps the index of its first child in bits 6..30 (bit 31 is LEAF_BIT), so all
+// wide trees of a scene together may hold at most 2^25 child records. Both builders (host and
+// device) check their totals against this before they hand out indices.
+constexpr uint64_t MAX_WIDE_CHILDREN = 1ull << 25;
+constexpr bool wide_children_fit(uint64_t n_children_total) { return n_children_total < MAX_WIDE_CHILDREN; }
+constexpr uint32_t wide_ref(uint32_t first_child, uint32_t count) { return (first_child << 6) | (count - 1u); }
 
 struct Result {
     std::vector<Node4> nodes;     // nodes[0] is the root (always an inner node)

@@ -211,7 +211,7 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
 // primary_stats: null, or receives the counters as they stand after the camera-ray kernel.
 int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
                   hipStream_t stream, void* const* events = nullptr, DevStats* primary_stats = nullptr,
-                  bool* projected = nullptr) {
+                  bool* projected = nullptr, DevStats* bounce_stats = nullptr) {
     auto mark = [&](int k) -> hipError_t {
         return events ? hipEventRecord((hipEvent_t)events[k], stream) : hipSuccess;
     };
@@ -257,7 +257,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (!pipeline) {
         HIP_TRY(mark(0));
         HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
-        for (int k = 1; k < RT_RENDER_EVENTS; ++k) HIP_TRY(mark(k));
+        for (int k = 1; k < RT_RENDER_EVENTS; ++k) HIP_TRY(mark(k));  // [5], [6] with the rest
         if (primary_stats && d_stats) {
             HIP_TRY(hipStreamSynchronize(stream));
             HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
@@ -387,12 +387,30 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 HIP_TRY(hipMemsetAsync(bw.state + tr.level_rays, 0, deeper * 4, stream));
                 HIP_TRY(hipMemsetAsync(bw.keys[0] + tr.level_rays, 0xFF, deeper * 4, stream));
             }
+            if (last_run) HIP_TRY(mark(5));
+            DevStats before_bounce{};
+            if (bounce_stats && d_stats) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipMemcpy(&before_bounce, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
+            }
             for (uint32_t level = 0; level < tr.levels; ++level) {
                 uint32_t* counter = nullptr;
                 rc = take_counter(s->ctx, stream, &counter);
                 if (rc != RT_OK) return rc;
                 HIP_TRY(rtk::wf_bounce(s->view, dp, lp2, tr, level, d_list, counter, w.samp, w.state, bw.samp, bw.state,
                                        bw.keys[0], bw.order, bw.counts, d_stats, stream));
+            }
+            if (last_run) HIP_TRY(mark(6));
+            if (bounce_stats && d_stats) {
+                // What the bounce launches of this run of tiles added to the counters.
+                DevStats after{};
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipMemcpy(&after, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
+                bounce_stats->rays += after.rays - before_bounce.rays;
+                bounce_stats->box_tests += after.box_tests - before_bounce.box_tests;
+                bounce_stats->tri_tests += after.tri_tests - before_bounce.tri_tests;
+                bounce_stats->node_visits += after.node_visits - before_bounce.node_visits;
+                bounce_stats->fetch_bytes += after.fetch_bytes - before_bounce.fetch_bytes;
             }
             size_t tb2 = bw.temp_bytes;
             HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], nullptr, bw.order, n_rays,
@@ -405,6 +423,10 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         }
     }
     HIP_TRY(mark(4));
+    if (mode != 2) {
+        HIP_TRY(mark(5));
+        HIP_TRY(mark(6));
+    }
     if (raster) w.zbuf_clean = true;
     return RT_OK;
 }
@@ -621,7 +643,11 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);
             s->wide_depth = std::max(s->wide_depth, L.depth_wide);
         }
-        if (n_wide_total >= (1u << 26)) return rt_fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+        // The reservation fixes the child indices the device builder hands out, so it is what must
+        // fit an inner reference (the host build below checks the records it actually made).
+        if (!rtbvh::wide_children_fit(n_wide_total))
+            return rt_fail(RT_ERR_UNSUPPORTED, "wide tree too large for the device build (%zu child records reserved, limit %llu)",
+                           n_wide_total, (unsigned long long)rtbvh::MAX_WIDE_CHILDREN);
     }
     if (s->max_stack > RT_STACK_MAX || s->wide_depth > RT_BEAM_LEVELS) return rt_fail(RT_ERR_UNSUPPORTED, "tree too deep");
     for (uint32_t o = 0; !device_build && o < n_objs; ++o) {
@@ -647,7 +673,8 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
         if (res.max_stack > RT_STACK_MAX || res.wide_depth > RT_BEAM_LEVELS)
             return rt_fail(RT_ERR_UNSUPPORTED, "object %u: tree too deep (%u pending entries, %u wide levels)", o,
                         res.max_stack, res.wide_depth);
-        if (wide_all.size() + res.wide.size() >= (1u << 25)) return rt_fail(RT_ERR_UNSUPPORTED, "wide tree too large");
+        if (!rtbvh::wide_children_fit(wide_all.size() + res.wide.size()))
+            return rt_fail(RT_ERR_UNSUPPORTED, "wide tree too large");
         ob.wide_root = res.wide_root;
         wide_all.insert(wide_all.end(), res.wide.begin(), res.wide.end());
         s->max_stack = std::max(s->max_stack, res.max_stack);
@@ -762,6 +789,10 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
                 used_wide += L.n_wide;
             }
         }
+        // The fixed fan-out fallback has a depth of its own (a small RAYS_HIP_WIDE makes it deep).
+        if (s->max_stack > RT_STACK_MAX || s->wide_depth > RT_BEAM_LEVELS)
+            return rt_fail(RT_ERR_UNSUPPORTED, "device-built tree too deep (%u pending entries, %u wide levels)",
+                           s->max_stack, s->wide_depth);
         s->sizes[0] = used_wide * sizeof(rtbvh::Child);
         s->sizes[1] = used_nodes * sizeof(rtbvh::Node4);
         if (std::getenv("RAYS_HIP_VERBOSE"))
@@ -956,9 +987,9 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     DevStats* d_stats;
     HIP_TRY(tmp.alloc((void**)&d_stats, sizeof(DevStats)));
     HIP_TRY(hipMemset(d_stats, 0, sizeof(DevStats)));
-    DevStats hp{};
+    DevStats hp{}, hb{};
     bool projected = false;
-    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp, &projected);
+    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp, &projected, &hb);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     DevStats h;
@@ -974,6 +1005,11 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     stats->primary_node_visits = hp.node_visits;
     stats->primary_fetch_bytes = hp.fetch_bytes;
     stats->camera_by_projection = projected ? 1u : 0u;
+    stats->bounce_rays = hb.rays;
+    stats->bounce_box_tests = hb.box_tests;
+    stats->bounce_tri_tests = hb.tri_tests;
+    stats->bounce_node_visits = hb.node_visits;
+    stats->bounce_fetch_bytes = hb.fetch_bytes;
     if (std::getenv("RAYS_HIP_VERBOSE"))
         std::fprintf(stderr,
                      "rays_hip: camera kernel: %llu beam walks, %llu mask walks, %llu refits, %llu mask-walk nodes; "

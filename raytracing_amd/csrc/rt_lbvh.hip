@@ -28,7 +28,10 @@ using rtbvh::Node4;
 
 namespace {
 
-constexpr float PAD_REL = 6e-6f;  // relative widening of every triangle box, as in the host build
+// Widening of every triangle box, as in the host build: relative to the box's own coordinates plus
+// an absolute part tied to the object's largest coordinate (see bvh_build.cpp).
+constexpr float PAD_REL = 6e-6f;
+constexpr float PAD_ABS = 1e-6f;
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {
     v &= 0x3FFu;
@@ -71,7 +74,7 @@ __global__ void k_lbvh_codes(const float* __restrict__ verts, const uint32_t* __
 // Leaf level of both trees: record p of the object holds triangle sorted[p].
 __global__ void k_lbvh_leaves(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
                               const uint32_t* __restrict__ sorted, uint32_t n, uint32_t tri_base, uint32_t rec_base,
-                              Child* __restrict__ wide0, Node4* __restrict__ nodes0, uint32_t* __restrict__ order) {
+                              float abs_pad, Child* __restrict__ wide0, Node4* __restrict__ nodes0, uint32_t* __restrict__ order) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint32_t t = sorted[p];
@@ -80,7 +83,7 @@ __global__ void k_lbvh_leaves(const float* __restrict__ verts, const uint32_t* _
     Child c;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float pad = fmaxf(fabsf(lo[k]), fabsf(hi[k])) * PAD_REL + 1e-30f;
+        const float pad = fmaxf(fabsf(lo[k]), fabsf(hi[k])) * PAD_REL + abs_pad;
         c.lo[k] = lo[k] - pad;
         c.hi[k] = hi[k] + pad;
     }
@@ -382,6 +385,13 @@ LbvhLayout lbvh_layout(uint32_t n, uint32_t fan) {
     return L;
 }
 
+// PAD_ABS times the object's largest coordinate (its box holds every vertex).
+static float abs_pad_of(const float bbmin[3], const float bbmax[3]) {
+    float m = 0.0f;
+    for (int k = 0; k < 3; ++k) m = fmaxf(m, fmaxf(fabsf(bbmin[k]), fabsf(bbmax[k])));
+    return m * PAD_ABS + 1e-30f;
+}
+
 hipError_t lbvh_build(const float* d_verts, const uint32_t* d_tris, uint32_t n, const float bbmin[3], const float bbmax[3],
                       uint32_t tri_base, uint32_t rec_base, uint32_t node_base, uint32_t wide_base, uint32_t fan,
                       Node4* d_nodes_all, Child* d_wide_all, uint32_t* d_order_all, uint32_t* d_keys[2],
@@ -401,7 +411,7 @@ hipError_t lbvh_build(const float* d_verts, const uint32_t* d_tris, uint32_t n, 
     Node4* nodes = d_nodes_all + node_base;
     Child* wide = d_wide_all + wide_base;
     hipLaunchKernelGGL(k_lbvh_leaves, dim3(blocks_for(n)), dim3(256), 0, s, d_verts, d_tris, d_vals[1], n, tri_base,
-                       rec_base, wide, nodes, d_order_all + rec_base);
+                       rec_base, abs_pad_of(bbmin, bbmax), wide, nodes, d_order_all + rec_base);
     // 4-wide levels.
     uint32_t in_off = 0, count = (n + 3u) / 4u;
     while (count > 1u) {
@@ -469,7 +479,7 @@ hipError_t lbvh_build_radix(const float* d_verts, const uint32_t* d_tris, uint32
     // are rewritten by the collapse, which reads boxes[] only), the 4-wide level-0 writes land in
     // nodes[0 .. n/4) and are overwritten likewise.
     hipLaunchKernelGGL(k_lbvh_leaves, dim3(blocks_for(n)), dim3(256), 0, s, d_verts, d_tris, d_vals[1], n, tri_base,
-                       rec_base, wide, nodes, d_order_all + rec_base);
+                       rec_base, abs_pad_of(bbmin, bbmax), wide, nodes, d_order_all + rec_base);
     e = hipMemsetAsync(arrived, 0, (size_t)n * 4, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_radix_tree, dim3(blocks_for(n)), dim3(256), 0, s, d_keys[1], (int)n, left, right, parent,

@@ -16,6 +16,13 @@ pub struct rt_scene {
     _private: [u8; 0],
 }
 
+/// The 128 bytes of an RCCL unique id (rank 0 makes it, every rank needs it).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rt_comm_id {
+    pub bytes: [c_char; 128],
+}
+
 #[repr(C)]
 pub struct rt_object_desc {
     pub verts: *const f32,
@@ -72,6 +79,11 @@ pub struct rt_stats {
     pub fetch_bytes: u64,
     pub primary_fetch_bytes: u64,
     pub camera_by_projection: u64,
+    pub bounce_rays: u64,
+    pub bounce_box_tests: u64,
+    pub bounce_tri_tests: u64,
+    pub bounce_node_visits: u64,
+    pub bounce_fetch_bytes: u64,
 }
 
 extern "C" {
@@ -98,6 +110,13 @@ extern "C" {
     pub fn rt_render_device_stats(scene: *mut rt_scene, p: *const rt_render_params, d_rgba8: *mut u8, d_hit_ids: *mut u32, stats: *mut rt_stats) -> c_int;
     pub fn rt_shard_tiles(width: u32, height: u32, shard_index: u32, shard_count: u32) -> u32;
     pub fn rt_deinterleave_tiles_device(ctx: *mut rt_ctx, d_gathered: *const u8, slab_tiles: u32, width: u32, height: u32, shard_count: u32, d_rgba8: *mut u8, stream: *mut c_void) -> c_int;
+    /// The frame's one exchange step: every rank's tile slab to rank 0 over RCCL, then the scatter
+    /// into the frame. `nccl_comm` is an `ncclComm_t`.
+    pub fn rt_gather_tiles_device(ctx: *mut rt_ctx, nccl_comm: *mut c_void, d_slab: *const u8, width: u32, height: u32, d_rgba8: *mut u8, stream: *mut c_void) -> c_int;
+    pub fn rt_comm_id_create(out: *mut rt_comm_id) -> c_int;
+    pub fn rt_comm_create(ctx: *mut rt_ctx, id: *const rt_comm_id, rank: c_int, n_ranks: c_int, nccl_comm: *mut *mut c_void) -> c_int;
+    pub fn rt_comm_ranks(nccl_comm: *mut c_void, rank: *mut c_int, n_ranks: *mut c_int) -> c_int;
+    pub fn rt_comm_destroy(nccl_comm: *mut c_void) -> c_int;
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_version() -> *const c_char;
 }

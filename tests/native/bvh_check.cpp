@@ -133,3 +133,15 @@ extern "C" int bvh_check(const float* bounds, uint32_t n, uint32_t width, int th
     if (out[5] > r.max_stack) return 7;
     return 0;
 }
+
+// The arithmetic of the wide tree's size limit: the largest child index the builders may hand out
+// still leaves LEAF_BIT clear in an inner reference of a full node; the first index beyond it would not.
+extern "C" int bvh_wide_limit_check(void) {
+    const uint64_t last = rtbvh::MAX_WIDE_CHILDREN - 1;
+    if (!rtbvh::wide_children_fit(last) || rtbvh::wide_children_fit(rtbvh::MAX_WIDE_CHILDREN)) return 1;
+    const uint32_t ref = rtbvh::wide_ref((uint32_t)last, rtbvh::MAX_WIDE);
+    if (ref & LEAF_BIT) return 2;
+    if ((ref >> 6) != (uint32_t)last || (ref & 63u) + 1u != rtbvh::MAX_WIDE) return 3;
+    if (!(rtbvh::wide_ref((uint32_t)rtbvh::MAX_WIDE_CHILDREN, 1u) & LEAF_BIT)) return 4;
+    return 0;
+}

@@ -503,7 +503,7 @@ def test_device_entry_points_match_host_entry_points(teapot_pair):
 
 
 def test_render_events_stats_and_sizes(soup_pair):
-    """rt_render_device_events records its five events in order on the caller's stream and renders
+    """rt_render_device_events records its events in order on the caller's stream and renders
     the same frame as rt_render; rt_render_device_stats counts every search once; rt_scene_sizes
     reports the arrays the counters refer to."""
     import ctypes
@@ -516,7 +516,7 @@ def test_render_events_stats_and_sizes(soup_pair):
     ref, ids = g.render(p, want_hit_ids=True)
     hip = ctypes.CDLL("libamdhip64.so")
     evs = []
-    for _ in range(5):
+    for _ in range(7):
         e = ctypes.c_void_p()
         assert hip.hipEventCreate(ctypes.byref(e)) == 0
         evs.append(e)
@@ -533,7 +533,9 @@ def test_render_events_stats_and_sizes(soup_pair):
     for e in evs:
         hip.hipEventDestroy(e)
     with pytest.raises(Exception):
-        g.render_device_events(p, frame.data_ptr(), [0] * 5, None, stream.cuda_stream)
+        g.render_device_events(p, frame.data_ptr(), [0] * 7, None, stream.cuda_stream)
+    with pytest.raises(Exception):
+        g.render_device_events(p, frame.data_ptr(), [e.value for e in evs[:5]], None, stream.cuda_stream)
 
     st = g.render_device_stats(p, frame.data_ptr())
     n = W * H * 4
@@ -581,3 +583,30 @@ def test_device_built_tree_gives_the_same_answers(which, ctx, oracle, default_ob
     rgba, ids = g.render(render_params(W, H, 2, **kw), want_hit_ids=True)
     _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
     g.close()
+
+
+def test_gather_tiles_over_a_one_rank_rccl_communicator(ctx):
+    """rt_comm_id_create / rt_comm_create / rt_gather_tiles_device with the only communicator one GPU
+    allows: a single rank. Rank 0's own slab goes through the same copy and tile scatter as the
+    received ones."""
+    import torch
+
+    from raytracing_amd import Comm, comm_id_create
+    from raytracing_amd import distributed as rd
+
+    comm = Comm(ctx, comm_id_create(), 0, 1)
+    try:
+        assert comm.ranks() == (0, 1)
+        for (w, h) in ((200, 120), (64, 32)):      # the second, smaller frame reuses the receive slab
+            rng = np.random.default_rng(w)
+            slab = rd.slab_tiles(w, h, 1)
+            tiles = rng.integers(0, 256, size=(1, slab, 32, 32, 4), dtype=np.uint8)
+            d_slab = torch.from_numpy(tiles).cuda()
+            out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            comm.gather_tiles_device(d_slab.data_ptr(), w, h, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), rd.deinterleave_numpy(tiles, w, h, 1))
+        with pytest.raises(Exception):
+            comm.gather_tiles_device(d_slab.data_ptr(), w, h, None, 0)     # rank 0 needs the frame
+    finally:
+        comm.close()

@@ -334,6 +334,13 @@ def rtb_max_leaf():
     return 4
 
 
+def test_wide_tree_size_limit_keeps_inner_references_clear_of_the_leaf_bit(bvh_shim):
+    """Both builders refuse scenes whose wide trees would need 2^25 child records or more: an inner
+    reference is (first child << 6) | (count - 1) and bit 31 marks a leaf."""
+    bvh_shim.bvh_wide_limit_check.restype = ctypes.c_int
+    assert bvh_shim.bvh_wide_limit_check() == 0
+
+
 def test_sun_at_follows_the_reference_circle():
     """src/main.rs:476-484: (sin(t / 10) * 100000, 25000, cos(t / 10) * 100000) in single precision."""
     from raytracing_amd import scenes
