@@ -82,7 +82,7 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
     W, H = args.width, args.height
     # One run of tiles for the whole frame (the default workspace limit would cut this frame in two, and
     # the events around the bounce launches cover one run).
-    os.environ.setdefault("RAYS_HIP_BOUNCE_RAYS", str(W * H * 4 * 10 + 1))
+    os.environ.setdefault("RAYS_HIP_BOUNCE_RAYS", str(-(-W // 32) * -(-H // 32) * 1024 * 4 * 10))
     objects = scenes.soup(args.bounce_tris, 0x5EED0002)
     scene = Scene(ctx, objects)
     del objects
@@ -106,7 +106,7 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
     # out of samples * 10 ray slots: samples that hit nothing cast none). Algorithmic bytes of a
     # launch: per slot a 24-byte record out (hit point + id 16, state 4, sort key 4), per sample
     # its 20-byte record in, plus the 4-wide tree, the triangle records and the normals / colours once.
-    samples = st["primary_rays"]
+    samples = W * H * 4
     slots = samples * 10
     alg_bytes = 24 * slots + 20 * samples + sizes["nodes4"] + sizes["recs"] + sizes["tri_data"]
     flops = FLOP_BOX * st["bounce_box_tests"] + FLOP_TRI * st["bounce_tri_tests"]

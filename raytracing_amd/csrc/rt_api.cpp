@@ -68,6 +68,38 @@ int host_threads() {
 inline float g_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 inline float g_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
 
+// Relative growth of a projected triangle's bounding box that holds every camera sample the exact
+// triangle test can accept: the bound of raster_setup (rt_kernels.hip) in double precision, for
+// |dx| <= 1 (the reference's aspect of 1; wider frames grow it a little: an estimate for the work
+// limit, the kernel computes its own), with the edges rounded to float as pack_triangles stores them.
+// Infinity when the triangle's plane passes too close to the camera for a bound.
+double raster_grow(const float* a, const float* b, const float* c) {
+    double e1[3], e2[3], sv[3];
+    for (int k = 0; k < 3; ++k) {
+        e1[k] = (double)(float)(b[k] - a[k]);
+        e2[k] = (double)(float)(c[k] - a[k]);
+        sv[k] = -(double)a[k];
+    }
+    const double Dx = 1.0, Dy = 1.0;
+    auto ab = [](double v) { return std::fabs(v); };
+    const double r[3] = {sv[1] * e1[2] - sv[2] * e1[1], sv[2] * e1[0] - sv[0] * e1[2], sv[0] * e1[1] - sv[1] * e1[0]};
+    const double T = e2[0] * r[0] + e2[1] * r[1] + e2[2] * r[2];
+    const double qh[3] = {Dy * ab(e2[2]) + ab(e2[1]), ab(e2[0]) + Dx * ab(e2[2]), Dx * ab(e2[1]) + Dy * ab(e2[0])};
+    const double Mu = ab(sv[0]) * qh[0] + ab(sv[1]) * qh[1] + ab(sv[2]) * qh[2];
+    const double Ma = ab(e1[0]) * qh[0] + ab(e1[1]) * qh[1] + ab(e1[2]) * qh[2];
+    const double rh[3] = {ab(sv[1]) * ab(e1[2]) + ab(sv[2]) * ab(e1[1]), ab(sv[2]) * ab(e1[0]) + ab(sv[0]) * ab(e1[2]),
+                          ab(sv[0]) * ab(e1[1]) + ab(sv[1]) * ab(e1[0])};
+    const double Mv = Dx * rh[0] + Dy * rh[1] + rh[2];
+    const double Mt = ab(e2[0]) * rh[0] + ab(e2[1]) * rh[1] + ab(e2[2]) * rh[2];
+    const double U16 = 9.5367431640625e-7;
+    const double thr = U16 * (Mu + Mv + 2.0 * (Ma + Mu + Mv)) + 3e-37;
+    // Stricter than the kernel's own float test (|T| - 16 u Mt > 0), so that the two never disagree.
+    const double Tlow = ab(T) - 5.0 * U16 * Mt;
+    if (!(Tlow > 0.0)) return INFINITY;
+    const double zmax = std::max(std::max((double)a[2], (double)b[2]), (double)c[2]);
+    return thr * zmax / Tlow * 1.01;
+}
+
 }  // namespace
 
 
@@ -281,12 +313,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         tr.mirror = (reflective && p->reflect_depth > 1) ? 1u : 0u;
         tr.branches = tr.scatt + tr.mirror;
         tr.levels = tr.mirror ? p->reflect_depth - 1 : 1u;
-        // Secondary-ray records per run of tiles: at most 256 Mi (9 GB of workspace, allocated as far as
-        // a frame needs it); RAYS_HIP_BOUNCE_RAYS overrides. Fewer, larger runs are faster: the short
+        // Secondary-ray records per run of tiles: at most 512 Mi (18 GB of the GPU's 288 GB as workspace,
+        // allocated as far as a frame needs it); RAYS_HIP_BOUNCE_RAYS overrides. Fewer, larger runs are faster: the short
         // last run of a frame fills the device badly.
         const char* e = std::getenv("RAYS_HIP_BOUNCE_RAYS");
         const long long v = e ? std::atoll(e) : 0;
-        const size_t cap = v > 0 ? (size_t)v : ((size_t)256 << 20);
+        const size_t cap = v > 0 ? (size_t)v : ((size_t)512 << 20);
         const size_t per_tile = (size_t)tile_slots * tr.branches * tr.levels;
         if (per_tile >= (1ull << 31)) return rt_fail(RT_ERR_UNSUPPORTED, "too many secondary rays per tile");
         run_tiles = (uint32_t)std::min<size_t>(dp.n_tiles, std::max<size_t>(1, cap / per_tile));
@@ -300,14 +332,16 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     }
     FrameWork& w = s->work;
     FrameWork& bw = s->bounce_work;
-    // Camera rays by projection, unless a triangle would cover more than 2048 blocks of 8 x 8 samples
+    // Camera rays by projection, unless a triangle would cover more than 16384 blocks of 8 x 8 samples
     // (one wave steps over a triangle's blocks) or the frame is taller than wide (aspect 0).
-    bool raster = s->raster_ok && p->width >= p->height && !env_is("RAYS_HIP_RASTER", '0');
+    bool raster = s->raster_ok && p->width >= p->height && p->width / p->height <= 4 &&
+                  (uint64_t)p->width * p->grid < 65536u && (uint64_t)p->height * p->grid < 65536u &&  // 16-bit sample coordinates
+                  !env_is("RAYS_HIP_RASTER", '0');
     if (raster) {
         const float aspect = (float)(p->width / p->height);
         const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
         const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
-        raster = bx * by <= 2048.0f;
+        raster = bx * by <= 16384.0f;   // a block no sample of which passes the half-planes costs ~25 instructions
         // Its work grows with the summed area of the triangles' boxes (every layer of depth is
         // tested), the tree walk's with the number of samples. Projection is taken while its
         // estimate stays at or below 64 sample slots per sample of the frame; measured camera +
@@ -587,20 +621,53 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
         if (ob.n_rest != 0) s->raster_ok = false;
         for (uint32_t i = 0; i < ob.n_tris && s->raster_ok; ++i) {
             const uint32_t* t = &tris_all[3 * (size_t)(ob.tri_base + i)];
+            const float *a = &verts_all[3 * (size_t)t[0]], *b = &verts_all[3 * (size_t)t[1]], *c = &verts_all[3 * (size_t)t[2]];
             float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-            for (int k = 0; k < 3; ++k) {
-                const float* v = &verts_all[3 * (size_t)t[k]];
+            for (const float* v : {a, b, c}) {
                 if (!(v[2] > 0.01f)) s->raster_ok = false;
                 const float px = v[0] / v[2], py = v[1] / v[2];
                 x0 = std::min(x0, px), x1 = std::max(x1, px);
                 y0 = std::min(y0, py), y1 = std::max(y1, py);
             }
-            if (!(x1 - x0 < INFINITY) || !(y1 - y0 < INFINITY)) s->raster_ok = false;
-            s->raster_dx = std::max(s->raster_dx, x1 - x0);
-            s->raster_dy = std::max(s->raster_dy, y1 - y0);
-            s->raster_sum_dx += x1 - x0;
-            s->raster_sum_dy += y1 - y0;
-            s->raster_sum_area += (double)(x1 - x0) * (y1 - y0);
+            // The projection kernel grows every triangle's box of samples by a bound on what the
+            // exact test's rounding can accept outside the projected triangle (raster_setup in
+            // rt_kernels.hip); the same bound here, so that the work estimate and the block limit
+            // see the boxes the kernel will step over. A triangle seen edge-on from the camera has
+            // no finite bound: such scenes take the tree walk.
+            double ex = (double)x1 - x0, ey = (double)y1 - y0;
+            const double grow = raster_grow(a, b, c);
+            if (grow < 1.0e3) {
+                ex *= 1.0 + 2.0 * grow;
+                ey *= 1.0 + 2.0 * grow;
+            } else {
+                ex = ey = INFINITY;
+            }
+            // The kernel also keeps a triangle's samples inside the projection of its reference leaf
+            // (the eight consecutive triangles it is packed with), which bounds edge-on triangles.
+            const uint32_t leaf = i >> 3, n_leaves = ob.n_tris >> 3;
+            if (leaf < (n_leaves & ~7u)) {
+                float lx0 = INFINITY, lx1 = -INFINITY, ly0 = INFINITY, ly1 = -INFINITY;
+                for (uint32_t j = leaf * 8; j < leaf * 8 + 8; ++j)
+                    for (int k = 0; k < 3; ++k) {
+                        const float* v = &verts_all[3 * (size_t)tris_all[3 * (size_t)(ob.tri_base + j) + k]];
+                        // corners of the leaf's box project no farther out than its vertices taken at
+                        // the leaf's nearest depth; the estimate only needs the extent
+                        lx0 = std::min(lx0, v[0] / v[2]), lx1 = std::max(lx1, v[0] / v[2]);
+                        ly0 = std::min(ly0, v[1] / v[2]), ly1 = std::max(ly1, v[1] / v[2]);
+                    }
+                ex = std::min(ex, 1.5 * ((double)lx1 - lx0));
+                ey = std::min(ey, 1.5 * ((double)ly1 - ly0));
+            }
+            if (!(ex < INFINITY) || !(ey < INFINITY)) {
+                s->raster_ok = false;
+                break;
+            }
+            const float dx = (float)ex, dy = (float)ey;
+            s->raster_dx = std::max(s->raster_dx, dx);
+            s->raster_dy = std::max(s->raster_dy, dy);
+            s->raster_sum_dx += dx;
+            s->raster_sum_dy += dy;
+            s->raster_sum_area += (double)dx * dy;
         }
     }
 

@@ -1805,7 +1805,7 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
 // and were 4 % slower.)
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_RASTER_TRIS
-#define RT_RASTER_TRIS 8
+#define RT_RASTER_TRIS 32
 #endif
 #define RT_ZKEY_NONE 0xFFFFFFFFFFFFFFFFull
 
@@ -1845,12 +1845,10 @@ __global__ void k_camera_table(SceneView sv, DevRenderParams p, float* __restric
     }
 }
 
-#ifndef RT_RASTER_SPAN
-#define RT_RASTER_SPAN 128
+#ifndef RT_RASTER_SLOP
+#define RT_RASTER_SLOP 0.125f   // samples: rounding of the projected vertices (hardware reciprocal, float products)
 #endif
-#ifndef RT_RASTER_MARGIN
-#define RT_RASTER_MARGIN 0.25f
-#endif
+#define RT_RASTER_QUEUE 128     // candidate samples a wave holds before it tests 64 of them
 // True when the shard owns one of the tiles that the sample rectangle [u0, u1] x [w0, w1] touches
 // (tile (tx, ty) belongs to shard (tx + ty) % count). gs = log2(samples per pixel side).
 __device__ __forceinline__ bool shard_touches(const DevRenderParams& p, uint32_t gs, int u0, int u1, int w0, int w1) {
@@ -1871,41 +1869,121 @@ __device__ __forceinline__ float bcast(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// |a| x |b| with every product taken positive: bounds the magnitude of the terms of a cross product.
+__device__ __forceinline__ rt_f3 abs_cross(rt_f3 a, rt_f3 b) {
+    const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
+    const float bx = __builtin_fabsf(b.x), by = __builtin_fabsf(b.y), bz = __builtin_fabsf(b.z);
+    return f3(ay * bz + az * by, az * bx + ax * bz, ax * by + ay * bx);
+}
+
+// What a camera ray's exact triangle test (tri_intersect with the origin at zero) can accept, bounded
+// from outside by three half-planes of the image plane. For d = (dx, dy, 1) the test's quantities
+// are linear in d:  a = d . (e2 x e1)... precisely, with s = -v0:
+//     U(d) = s . (d x e2) = d . (e2 x s)      (u = U / a)
+//     V(d) = d . (s x e1)                     (v = V / a)
+//     A(d) = e1 . (d x e2) = d . (e2 x e1)    (a)
+//     T    = e2 . (s x e1)                    (t = T / a; no d in it: one value per triangle)
+// A sample is accepted only if t > 0, so sign(a) = sign(T) =: sg, and then u >= 0, v >= 0,
+// u + v <= 1 say  sg U >= 0, sg V >= 0, sg (A - U - V) >= 0  up to rounding. Every computed
+// quantity differs from its exact value by at most 8 u M (u = 2^-24; M = the same expression with
+// every product taken positive, over |dx| <= Dx, |dy| <= Dy): cross products are a fused
+// multiply-subtract of a rounded product (3 u per component), dot products three more roundings.
+// The half-plane functions below are evaluated in float as fma(dx, gx, fma(dy, gy, gz)) from
+// float cross products: 5 u M more. A threshold of 16 u M (32 u M for the third, which sums three
+// quantities and a rounded u + v) plus a term that covers products underflowing to zero is
+// folded into gz, so that  F >= 0  holds for every sample the exact test can accept.
+// In barycentric coordinates of the projected triangle the three functions are lambda_b h_b,
+// lambda_c h_c, lambda_a h_a with h_k = |T| / z_k, so the accepted region is the triangle grown by
+// eps_k = threshold_k / h_k in each coordinate, and its bounding box is the vertices' box grown by
+// at most (eps_a + eps_b + eps_c) of its own extent: `grow`. A triangle whose |T| is not safely
+// above its own rounding error (seen edge-on from the camera) gets grow = infinity.
+struct RasterSetup {
+    rt_f3 gu, gv, gw;   // F_k(d) = fma(dx, g.x, fma(dy, g.y, g.z)), thresholds folded in
+    float grow;         // relative growth of the projected vertices' box that holds every accepted sample
+    bool visible;       // false: T is zero or NaN, no camera ray can be accepted
+};
+__device__ __forceinline__ RasterSetup raster_setup(rt_f3 e1, rt_f3 e2, rt_f3 v0, float Dx, float Dy, float zmax) {
+    RasterSetup rs;
+    const rt_f3 s = f3(0.0f, 0.0f, 0.0f) - v0;
+    const rt_f3 r = s_cross(s, e1);
+    const float T = s_dot(e2, r);             // exactly the test's e2 . r
+    rs.visible = (T > 0.0f) || (T < 0.0f);
+    const float sg = T < 0.0f ? -1.0f : 1.0f;
+    const rt_f3 gu = s_cross(e2, s), gv = r, ga = s_cross(e2, e1);
+    // magnitudes
+    const rt_f3 qh = f3(Dy * __builtin_fabsf(e2.z) + __builtin_fabsf(e2.y), __builtin_fabsf(e2.x) + Dx * __builtin_fabsf(e2.z),
+                        Dx * __builtin_fabsf(e2.y) + Dy * __builtin_fabsf(e2.x));
+    const float Mu = __builtin_fabsf(s.x) * qh.x + __builtin_fabsf(s.y) * qh.y + __builtin_fabsf(s.z) * qh.z;
+    const float Ma = __builtin_fabsf(e1.x) * qh.x + __builtin_fabsf(e1.y) * qh.y + __builtin_fabsf(e1.z) * qh.z;
+    const rt_f3 rh = abs_cross(s, e1);
+    const float Mv = Dx * rh.x + Dy * rh.y + rh.z;
+    const float Mt = __builtin_fabsf(e2.x) * rh.x + __builtin_fabsf(e2.y) * rh.y + __builtin_fabsf(e2.z) * rh.z;
+    const float U16 = 9.5367431640625e-7f;    // 16 u = 2^-20
+    const float tiny = 1e-37f + 1e-30f * Ma;  // a product f * U that underflows to zero passes the sign tests
+    const float thr_u = U16 * Mu + tiny, thr_v = U16 * Mv + tiny, thr_w = 2.0f * U16 * (Ma + Mu + Mv) + tiny;
+    rs.gu = f3(sg * gu.x, sg * gu.y, sg * gu.z + thr_u);
+    rs.gv = f3(sg * gv.x, sg * gv.y, sg * gv.z + thr_v);
+    rs.gw = f3(sg * (ga.x - gu.x - gv.x), sg * (ga.y - gu.y - gv.y), sg * (ga.z - gu.z - gv.z) + thr_w);
+    // |T| from below, and the growth of the box. z_k <= zmax.
+    const float Tlow = __builtin_fabsf(T) - U16 * Mt;
+    rs.grow = Tlow > 0.0f ? (thr_u + thr_v + thr_w) * zmax / Tlow * 1.0001f : RT_INF;
+    if (!(rs.grow >= 0.0f)) rs.grow = RT_INF;   // NaN from overflowing magnitudes
+    return rs;
+}
+
 // Counters of an instrumented run: tri = samples put through the triangle test, box = object box
 // tests, node = blocks of 8 x 8 samples stepped over, bytes = triangle data, table lines and
 // nearest-hit words asked for.
+// One wave takes RT_RASTER_TRIS consecutive triangles, one lane each for the set-up (data, box of
+// samples, half-planes). It then steps over each triangle's box in blocks of 8 x 8 samples; a sample
+// that passes the three half-planes is a candidate and goes into a queue in LDS (its ray direction,
+// its coordinates, its triangle's slot); whenever 64 candidates wait, the wave puts them through the
+// exact test together, every lane with its own triangle's data from LDS. The exact test, with its
+// division, thus runs on full waves of samples that are (nearly all) inside their triangles, instead
+// of on every sample of every box.
+struct RasterLds {
+    float tri[RT_RASTER_TRIS][12];            // e1 xyz, e2 xyz, v0 xyz, id, object, z slab near / far packed below
+    float4 queue[RT_RASTER_QUEUE];            // dx, dy, (su | sw << 16), slot
+};
+
 template <bool STATS>
 __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams p, uint32_t n_tris_total,
                                                   const float* __restrict__ tab,
                                                   unsigned long long* __restrict__ zbuf,
                                                   DevStats* __restrict__ stats) {
-    __shared__ float s_tab[6][RT_RASTER_SPAN];
+    __shared__ RasterLds lds;
     LaneStats st;
     const uint32_t lane = threadIdx.x;
     const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g);  // grid is a power of two
     const float aspect = (float)(p.width / p.height);
     const int gw = (int)(p.width * g), gh = (int)(p.height * g);
     const uint32_t L = (uint32_t)(gw + gh);
-    // Lane l < RT_RASTER_TRIS prepares triangle l of the wave: its data, its object and the box of
-    // samples its projection can touch.
+    // Lane l < RT_RASTER_TRIS prepares triangle l of the wave.
     const uint32_t my_id = blockIdx.x * RT_RASTER_TRIS + lane;
     const bool mine = lane < RT_RASTER_TRIS && my_id < n_tris_total;
-    rt_f3 me1 = f3(0.0f, 0.0f, 0.0f), me2 = me1, mv0 = me1;
     int mu0 = 0, mu1 = -1, mw0 = 0, mw1 = -1;
-    uint32_t moi = 0;
+    RasterSetup rs;
+    rs.gu = rs.gv = rs.gw = f3(0.0f, 0.0f, 0.0f);
+    rs.grow = 0.0f;
+    rs.visible = false;
     if (mine) {
+        uint32_t moi = 0;
         while (my_id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
         const float* t9 = sv.tri9 + 9 * (size_t)my_id;
-        me1 = ld3(t9), me2 = ld3(t9 + 3), mv0 = ld3(t9 + 6);
+        const rt_f3 me1 = ld3(t9), me2 = ld3(t9 + 3), mv0 = ld3(t9 + 6);
         if (STATS) st.bytes += 36;
         const rt_f3 vb = mv0 + me1, vc = mv0 + me2;
         mu0 = 0, mu1 = gw - 1, mw0 = 0, mw1 = gh - 1;
-        const float zmin = fminf(mv0.z, fminf(vb.z, vc.z));
-        if (zmin > 1e-3f) {
+        const float zmin = fminf(mv0.z, fminf(vb.z, vc.z)), zmax = fmaxf(mv0.z, fmaxf(vb.z, vc.z));
+        // |dx| <= aspect and |dy| <= 1 on the whole sample grid (src/main.rs:322-324).
+        rs = raster_setup(me1, me2, mv0, aspect, 1.0f, zmax * 1.000001f);
+        const DevObject& ob = sv.objs[moi];
+        const float ax = (float)gw * 0.5f / aspect, ay = (float)gh * 0.5f;
+        const float lim = 1.0e9f;
+        if (zmin > 1e-3f && rs.grow < RT_INF) {
             // Sample column of image-plane x: xx = (2 (x + o) / W - 1) * aspect, sample index
-            // (x + o) * g - 0.5. The hardware reciprocal will do: the margin covers its error and
-            // the rounding of the projection many times over.
-            const float ax = (float)gw * 0.5f / aspect, ay = (float)gh * 0.5f;
+            // (x + o) * g - 0.5. The hardware reciprocal will do: RT_RASTER_SLOP covers its error and
+            // the rounding of the products many times over.
             const float ia = __builtin_amdgcn_rcpf(mv0.z), ib = __builtin_amdgcn_rcpf(vb.z), ic = __builtin_amdgcn_rcpf(vc.z);
             const float xa = mv0.x * ia, xb = vb.x * ib, xc = vc.x * ic;
             const float ya = mv0.y * ia, yb = vb.y * ib, yc = vc.y * ic;
@@ -1913,86 +1991,166 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
             const float fu1 = (fmaxf(xa, fmaxf(xb, xc)) + aspect) * ax - 0.5f;
             const float fw0 = (1.0f - fmaxf(ya, fmaxf(yb, yc))) * ay - 0.5f;
             const float fw1 = (1.0f - fminf(ya, fminf(yb, yc))) * ay - 0.5f;
-            const float lim = 1.0e9f;
-            mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - RT_RASTER_MARGIN, -lim), lim)));
-            mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + RT_RASTER_MARGIN, -lim), lim)));
-            mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - RT_RASTER_MARGIN, -lim), lim)));
-            mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + RT_RASTER_MARGIN, -lim), lim)));
+            // The box that holds every sample the exact test can accept: the vertices' box grown by
+            // `grow` of its extent, the slop, and a relative part for sample coordinates in the
+            // tens of thousands.
+            const float mx = (fu1 - fu0) * rs.grow + RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fu0), __builtin_fabsf(fu1));
+            const float my = (fw1 - fw0) * rs.grow + RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fw0), __builtin_fabsf(fw1));
+            mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - mx, -lim), lim)));
+            mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + mx, -lim), lim)));
+            mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - my, -lim), lim)));
+            mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + my, -lim), lim)));
         }
+        // The reference tests a triangle only for rays that pass the slab test of its leaf: the box of
+        // the eight consecutive triangles it is packed with (src/main.rs:103-111, src/simd_accel.rs:342-377).
+        // With the origin at zero that test is  max_k(min_k * inv_k) <= min_k(max_k * inv_k),  products of
+        // rounded reciprocals: it can only pass for directions inside the projection of the leaf's box
+        // (all of it in front of the camera) widened by a few units of rounding, far inside the slop.
+        // That bounds the samples of a triangle whatever its own shape, edge-on ones included. (The
+        // leftover leaves at the end of an object go through the looser scalar test, src/main.rs:134-136,
+        // and are not bounded this way.)
+        const uint32_t leaf = (my_id - ob.tri_base) >> 3, n_leaves = ob.n_tris >> 3;
+        if (leaf < (n_leaves & ~7u)) {
+            const float* lb = sv.leaf_bounds + 6 * (size_t)(ob.leaf_base + leaf);
+            const rt_f3 lo = ld3(lb), hi = ld3(lb + 3);
+            if (STATS) st.bytes += 24;
+            if (lo.z > 1e-3f) {
+                const float in = __builtin_amdgcn_rcpf(lo.z), ifar = __builtin_amdgcn_rcpf(hi.z);
+                const float bx0 = lo.x * (lo.x < 0.0f ? in : ifar), bx1 = hi.x * (hi.x > 0.0f ? in : ifar);
+                const float by0 = lo.y * (lo.y < 0.0f ? in : ifar), by1 = hi.y * (hi.y > 0.0f ? in : ifar);
+                const float fu0 = (bx0 + aspect) * ax - 0.5f, fu1 = (bx1 + aspect) * ax - 0.5f;
+                const float fw0 = (1.0f - by1) * ay - 0.5f, fw1 = (1.0f - by0) * ay - 0.5f;
+                const float mx = RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fu0), __builtin_fabsf(fu1));
+                const float my = RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fw0), __builtin_fabsf(fw1));
+                mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - mx, -lim), lim)));
+                mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + mx, -lim), lim)));
+                mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - my, -lim), lim)));
+                mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + my, -lim), lim)));
+            }
+        }
+        float* td = lds.tri[lane];
+        td[0] = me1.x, td[1] = me1.y, td[2] = me1.z;
+        td[3] = me2.x, td[4] = me2.y, td[5] = me2.z;
+        td[6] = mv0.x, td[7] = mv0.y, td[8] = mv0.z;
+        td[9] = __uint_as_float(my_id);
+        // The object's box test (src/main.rs:101, src/objects.rs:322-333) with the origin at zero is
+        // g_min(t_near, 0) <= t_far. When the box holds the view axis on both lateral axes and reaches
+        // in front of the camera, one end of every lateral slab interval is >= 0 whatever the
+        // direction, and so is the far end along z: t_far >= 0, the test is true for every sample.
+        const bool always = ob.bbmin[0] < 0.0f && ob.bbmax[0] > 0.0f && ob.bbmin[1] < 0.0f && ob.bbmax[1] > 0.0f &&
+                            ob.bbmax[2] > 0.0f && ob.bbmin[2] > -RT_INF;
+        td[10] = __uint_as_float(moi | (always ? 0x80000000u : 0u));
+        td[11] = 0.0f;
     }
+    __syncthreads();
     unsigned long long todo =
-        __ballot(mine && mu0 <= mu1 && mw0 <= mw1 && shard_touches(p, gs, mu0, mu1, mw0, mw1));
+        __ballot(mine && rs.visible && mu0 <= mu1 && mw0 <= mw1 && shard_touches(p, gs, mu0, mu1, mw0, mw1));
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f);
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform: candidates lie at queue[(q_head .. q_tail) % RT_RASTER_QUEUE]
+
+    // Puts up to 64 waiting candidates through the exact test: the reference's arithmetic on the
+    // reference's ray, acceptance rule !failed && t > 0 (src/main.rs:117), then the object's box test.
+    auto test_candidates = [&](uint32_t n) {
+        const bool have = lane < n;
+        const float4 e = lds.queue[(q_head + (have ? lane : 0u)) % RT_RASTER_QUEUE];
+        q_head += n;
+        if (!have) return;
+        const float* td = lds.tri[__float_as_uint(e.w)];
+        const rt_f3 e1 = f3(td[0], td[1], td[2]), e2 = f3(td[3], td[4], td[5]), v0 = f3(td[6], td[7], td[8]);
+        const uint32_t id = __float_as_uint(td[9]), ow = __float_as_uint(td[10]);
+        const rt_f3 d = f3(e.x, e.y, 1.0f);
+        if (STATS) st.tri += 1;
+        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+        if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) return;
+        const uint32_t su = __float_as_uint(e.z) & 0xFFFFu, sw = __float_as_uint(e.z) >> 16;
+        if (!(ow & 0x80000000u)) {
+            // box_intersection_check from the tabulated slab intervals of this sample's column and row.
+            const uint32_t oi = ow;
+            const DevObject& ob = sv.objs[oi];
+            const float tz1 = (ob.bbmin[2] - 0.0f) * (1.0f / 1.0f), tz2 = (ob.bbmax[2] - 0.0f) * (1.0f / 1.0f);
+            const float nz = g_min(tz1, tz2), fz = g_max(tz1, tz2);
+            const float* near_tab = tab + (size_t)L * (1 + 2 * oi);
+            const float* far_tab = tab + (size_t)L * (2 + 2 * oi);
+            const float nx = near_tab[su], fx = far_tab[su], ny = near_tab[gw + sw], fy = far_tab[gw + sw];
+            if (STATS) st.box += 1, st.bytes += 16;
+            const float t_near = g_max(g_max(nx, ny), nz);
+            const float t_far = g_min(g_min(fx, fy), fz);
+            if (!(g_min(t_near, 0.0f) <= t_far)) return;
+        }
+        if (STATS) st.bytes += 8;
+        const uint32_t x = su >> gs, y = sw >> gs;
+        const uint32_t smp = sample_of(g, su & (g - 1u), sw & (g - 1u));
+        const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
+#ifdef RT_EXPERIMENT_PLAIN_STORE   // timing experiment only: wrong results
+        zbuf[((size_t)y * p.width + x) * p.spp + smp] = key;
+#else
+        atomicMin(&zbuf[((size_t)y * p.width + x) * p.spp + smp], key);
+#endif
+    };
+
     while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1ull;
-        const uint32_t id = blockIdx.x * RT_RASTER_TRIS + (uint32_t)l;
-        const rt_f3 e1 = f3(bcast(me1.x, l), bcast(me1.y, l), bcast(me1.z, l));
-        const rt_f3 e2 = f3(bcast(me2.x, l), bcast(me2.y, l), bcast(me2.z, l));
-        const rt_f3 v0 = f3(bcast(mv0.x, l), bcast(mv0.y, l), bcast(mv0.z, l));
+        const rt_f3 gu = f3(bcast(rs.gu.x, l), bcast(rs.gu.y, l), bcast(rs.gu.z, l));
+        const rt_f3 gv = f3(bcast(rs.gv.x, l), bcast(rs.gv.y, l), bcast(rs.gv.z, l));
+        const rt_f3 gwv = f3(bcast(rs.gw.x, l), bcast(rs.gw.y, l), bcast(rs.gw.z, l));
         const int u0 = __builtin_amdgcn_readlane(mu0, l), u1 = __builtin_amdgcn_readlane(mu1, l);
         const int w0 = __builtin_amdgcn_readlane(mw0, l), w1 = __builtin_amdgcn_readlane(mw1, l);
-        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)moi, l);
-        const DevObject& ob = sv.objs[oi];
-        // The z slab of the object's box test: inv_dir.z = 1 / 1.
-        const float tz1 = (ob.bbmin[2] - 0.0f) * (1.0f / 1.0f), tz2 = (ob.bbmax[2] - 0.0f) * (1.0f / 1.0f);
-        const float nz = g_min(tz1, tz2), fz = g_max(tz1, tz2);
-        const float* near_tab = tab + (size_t)L * (1 + 2 * oi);
-        const float* far_tab = tab + (size_t)L * (2 + 2 * oi);
-        // The table lines of the triangle's box go through LDS (one round trip to memory per
-        // triangle instead of two per block of samples); a box of more than RT_RASTER_SPAN lines
-        // a side reads the table directly.
-        const int ncol = u1 - u0 + 1, nrow = w1 - w0 + 1;
-        const bool staged = ncol <= RT_RASTER_SPAN && nrow <= RT_RASTER_SPAN;
-        if (staged) {
-            for (int i = (int)lane; i < RT_RASTER_SPAN; i += 64) {
-                if (STATS) st.bytes += 12 * ((i < ncol) + (i < nrow));
-                if (i < ncol) {
-                    s_tab[0][i] = tab[u0 + i];
-                    s_tab[1][i] = near_tab[u0 + i];
-                    s_tab[2][i] = far_tab[u0 + i];
-                }
-                if (i < nrow) {
-                    s_tab[3][i] = tab[gw + w0 + i];
-                    s_tab[4][i] = near_tab[gw + w0 + i];
-                    s_tab[5][i] = far_tab[gw + w0 + i];
-                }
+        // Blocks of 8 x 8 samples, 64 at a time with one lane per block: a block all of whose samples
+        // lie outside one of the half-planes is dropped before the wave looks at its samples. The
+        // table's columns increase with the sample index and its rows decrease, fma is monotone in
+        // each argument and so is its rounding, so a function evaluated at the block's best corner
+        // bounds what the samples of the block will evaluate to.
+        const uint32_t nbx = (uint32_t)(u1 - u0) / 8u + 1u, nby = (uint32_t)(w1 - w0) / 8u + 1u, nblocks = nbx * nby;
+        for (uint32_t base = 0; base < nblocks; base += 64u) {
+            const uint32_t b = base + lane;
+            const uint32_t brow = b / nbx, bcol = b - brow * nbx;
+            const int mbx = u0 + 8 * (int)bcol, mby = w0 + 8 * (int)brow;
+            bool keep = b < nblocks;
+            if (keep) {
+                const int ex = min(mbx + 7, u1), ey = min(mby + 7, w1);
+                keep = shard_touches(p, gs, mbx, ex, mby, ey);
+                const float dx_lo = tab[mbx], dx_hi = tab[ex], dy_hi = tab[gw + mby], dy_lo = tab[gw + ey];
+                if (STATS) st.bytes += 16;
+                const float fu = __builtin_fmaf(gu.x < 0.0f ? dx_lo : dx_hi, gu.x, __builtin_fmaf(gu.y < 0.0f ? dy_lo : dy_hi, gu.y, gu.z));
+                const float fv = __builtin_fmaf(gv.x < 0.0f ? dx_lo : dx_hi, gv.x, __builtin_fmaf(gv.y < 0.0f ? dy_lo : dy_hi, gv.y, gv.z));
+                const float fw = __builtin_fmaf(gwv.x < 0.0f ? dx_lo : dx_hi, gwv.x, __builtin_fmaf(gwv.y < 0.0f ? dy_lo : dy_hi, gwv.y, gwv.z));
+                keep = keep && !(fu < 0.0f) && !(fv < 0.0f) && !(fw < 0.0f);
             }
-        }
-        for (int by = w0; by <= w1; by += 8) {
-            const int sw = by + (int)(lane >> 3);
-            const bool row_ok = sw <= w1;
-            const int swc = row_ok ? sw : w1;
-            float dy, ny, fy;
-            if (staged) dy = s_tab[3][swc - w0], ny = s_tab[4][swc - w0], fy = s_tab[5][swc - w0];
-            else dy = tab[gw + swc], ny = near_tab[gw + swc], fy = far_tab[gw + swc];
-            for (int bx = u0; bx <= u1; bx += 8) {
-                // Blocks on other shards' tiles are passed over by the whole wave.
-                if (!shard_touches(p, gs, bx, min(bx + 7, u1), by, min(by + 7, w1))) continue;
-                const int su = bx + (int)(lane & 7u);
+            unsigned long long bm = __ballot(keep);
+            while (bm) {
+                const int j = __builtin_ctzll(bm);
+                bm &= bm - 1ull;
+                const int bx = __builtin_amdgcn_readlane(mbx, j), by = __builtin_amdgcn_readlane(mby, j);
+                const int su = bx + (int)(lane & 7u), sw = by + (int)(lane >> 3);
                 if (STATS && lane == 0) st.node += 1;
-                if (su > u1 || !row_ok) continue;
-                // A shard keeps the samples of its own tiles only: tile (tx, ty) belongs to shard (tx + ty) % count.
-                if (!shard_touches(p, gs, su, su, sw, sw)) continue;
-                float dx, nx, fx;
-                if (staged) dx = s_tab[0][su - u0], nx = s_tab[1][su - u0], fx = s_tab[2][su - u0];
-                else dx = tab[su], nx = near_tab[su], fx = far_tab[su];
-                const rt_f3 d = f3(dx, dy, 1.0f);
-                if (STATS) st.tri += 1, st.bytes += staged ? 0 : 12;
-                const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
-                if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
-                if (STATS) st.box += 1, st.bytes += 8;
-                // box_intersection_check (src/objects.rs:322-333) from the tabulated slab intervals.
-                const float t_near = g_max(g_max(nx, ny), nz);
-                const float t_far = g_min(g_min(fx, fy), fz);
-                if (!(g_min(t_near, 0.0f) <= t_far)) continue;
-                const uint32_t x = (uint32_t)su >> gs, y = (uint32_t)sw >> gs;
-                const uint32_t smp = sample_of(g, (uint32_t)su & (g - 1u), (uint32_t)sw & (g - 1u));
-                const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
-                unsigned long long* zp = &zbuf[((size_t)y * p.width + x) * p.spp + smp];
-                atomicMin(zp, key);
+                // A shard keeps the samples of its own tiles only.
+                const bool in = su <= u1 && sw <= w1 && shard_touches(p, gs, su, su, sw, sw);
+                const float dx = tab[in ? su : u1], dy = tab[gw + (in ? sw : w1)];
+                if (STATS) st.bytes += in ? 8 : 0;
+                // !(F < 0) rather than F >= 0: a function that overflowed to NaN must not reject.
+                const bool cand = in && !(__builtin_fmaf(dx, gu.x, __builtin_fmaf(dy, gu.y, gu.z)) < 0.0f) &&
+                                  !(__builtin_fmaf(dx, gv.x, __builtin_fmaf(dy, gv.y, gv.z)) < 0.0f) &&
+                                  !(__builtin_fmaf(dx, gwv.x, __builtin_fmaf(dy, gwv.y, gwv.z)) < 0.0f);
+                const unsigned long long cm = __ballot(cand);
+                if (cm == 0ull) continue;
+                if (cand) {
+                    const uint32_t pos = q_tail + (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull));
+                    lds.queue[pos % RT_RASTER_QUEUE] =
+                        make_float4(dx, dy, __uint_as_float((uint32_t)su | ((uint32_t)sw << 16)), __uint_as_float((uint32_t)l));
+                }
+                q_tail += (uint32_t)__builtin_popcountll(cm);
+                if (q_tail - q_head >= 64u) {
+                    __syncthreads();
+                    test_candidates(64u);
+                    __syncthreads();
+                }
             }
         }
+    }
+    if (q_tail != q_head) {
+        __syncthreads();
+        test_candidates(q_tail - q_head);
     }
     if (STATS) flush_stats(st, stats);
 }
