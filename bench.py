@@ -379,6 +379,8 @@ def main():
                 "phase_ms": {"camera_rays": phase_ms[0], "shadow_sort": phase_ms[1], "shadow_rays": phase_ms[2],
                              "resolve": phase_ms[3]},
                 "camera_rays_by": "projection of the triangles onto the sample grid" if projected else "beam walk",
+                "camera_phase_counters": {"triangle_tests": st["primary_tri_tests"], "object_box_tests": st["primary_box_tests"],
+                                          "node_visits_or_sample_blocks": st["primary_node_visits"]},
                 "scene_build_s": build_s,
                 "parallelism": f"tiles{world}" if world > 1 else "single",
                 "sharded_frame_equals_whole_frame": frame_ok,

@@ -363,7 +363,50 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (projected) *projected = raster;
     const uint32_t total_tiles = dp.n_tiles;
     HIP_TRY(mark(0));
+    // Projection runs tile by tile (triangle lists per tile of 32 x 32 samples, nearest hits in LDS);
+    // RAYS_HIP_RASTER=atomic keeps the older form with one nearest-hit word per sample in device memory.
+    const bool raster_by_tile = raster && !env_is("RAYS_HIP_RASTER", 'a');
     if (raster) {
+        const size_t tab = (1 + 2 * s->objects.size()) * ((size_t)p->width + p->height) * p->grid;
+        if (w.cam_table_floats < tab) {
+            if (w.cam_table) (void)hipFree(w.cam_table);
+            w.cam_table = nullptr;
+            w.cam_table_floats = 0;
+            HIP_TRY(hipMalloc((void**)&w.cam_table, tab * 4));
+            w.cam_table_floats = tab;
+        }
+    }
+    if (raster_by_tile) {
+        const uint32_t n_rt = ceil_div(p->width * p->grid, 32u) * ceil_div(p->height * p->grid, 32u);
+        if (w.bin_tiles < n_rt) {
+            if (w.bin_counts) (void)hipFree(w.bin_counts);
+            if (w.bin_offsets) (void)hipFree(w.bin_offsets);
+            w.bin_counts = w.bin_offsets = nullptr;
+            w.bin_tiles = 0;
+            HIP_TRY(hipMalloc((void**)&w.bin_counts, ((size_t)n_rt + 1) * 4));
+            HIP_TRY(hipMalloc((void**)&w.bin_offsets, ((size_t)n_rt + 1) * 4));
+            w.bin_tiles = n_rt;
+        }
+        HIP_TRY(rtk::raster_bin(s->view, dp, n_packed, w.cam_table, n_rt, w.bin_counts, w.bin_offsets, w.bin_list,
+                                (uint32_t)w.bin_capacity, false, stream));
+        const uint32_t key[5] = {p->width, p->height, p->grid, p->shard_index, p->shard_count};
+        if (!w.bin_list || std::memcmp(key, w.bin_key, sizeof(key)) != 0) {
+            // First frame of this shape: the lists' total length, read back once.
+            uint32_t total = 0;
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(&total, w.bin_offsets + n_rt, 4, hipMemcpyDeviceToHost));
+            if (w.bin_capacity < total || !w.bin_list) {
+                if (w.bin_list) (void)hipFree(w.bin_list);
+                w.bin_list = nullptr;
+                w.bin_capacity = 0;
+                HIP_TRY(hipMalloc((void**)&w.bin_list, std::max<size_t>(total, 4) * 4));
+                w.bin_capacity = std::max<size_t>(total, 4);
+            }
+            std::memcpy(w.bin_key, key, sizeof(key));
+        }
+        HIP_TRY(rtk::raster_bin(s->view, dp, n_packed, w.cam_table, n_rt, w.bin_counts, w.bin_offsets, w.bin_list,
+                                (uint32_t)w.bin_capacity, true, stream));
+    } else if (raster) {
         const size_t words = (size_t)p->width * p->height * spp;
         if (w.zbuf_words < words) {
             if (w.zbuf) (void)hipFree(w.zbuf);
@@ -372,14 +415,6 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(hipMalloc((void**)&w.zbuf, words * 8));
             w.zbuf_words = words;
             w.zbuf_clean = false;
-        }
-        const size_t tab = (1 + 2 * s->objects.size()) * ((size_t)p->width + p->height) * p->grid;
-        if (w.cam_table_floats < tab) {
-            if (w.cam_table) (void)hipFree(w.cam_table);
-            w.cam_table = nullptr;
-            w.cam_table_floats = 0;
-            HIP_TRY(hipMalloc((void**)&w.cam_table, tab * 4));
-            w.cam_table_floats = tab;
         }
         const bool clear = !w.zbuf_clean;
         w.zbuf_clean = false;  // until the record pass has been through every tile of this frame
@@ -391,7 +426,10 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         dp.n_tiles = std::min(run_tiles, total_tiles - first);
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
         const LightProj lp = light_projection(s, p, n_slots);
-        if (raster) {
+        if (raster_by_tile) {
+            HIP_TRY(rtk::raster_tiles(s->view, dp, lp, d_list, w.cam_table, w.bin_offsets, w.bin_list, w.samp, w.state,
+                                      w.keys[0], d_stats, stream));
+        } else if (raster) {
             HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], d_stats, stream));
         } else {
             HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, stream));
@@ -461,7 +499,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         HIP_TRY(mark(5));
         HIP_TRY(mark(6));
     }
-    if (raster) w.zbuf_clean = true;
+    if (raster && !raster_by_tile) w.zbuf_clean = true;
     return RT_OK;
 }
 

@@ -73,10 +73,20 @@ struct FrameWork {
     bool zbuf_clean = false;             // every word says "none" (the record pass of a whole frame leaves it so)
     float* cam_table = nullptr;  // image-plane coordinates of the sample columns and rows
     size_t cam_table_floats = 0;
+    // Projection by screen tile: triangles per raster tile (counts, then fill cursors), list offsets,
+    // the lists. The lists' total length depends on the scene (immutable) and on the frame described by
+    // bin_key only, so it is read back once per such frame and kept.
+    uint32_t* bin_counts = nullptr;
+    uint32_t* bin_offsets = nullptr;
+    size_t bin_tiles = 0;
+    uint32_t* bin_list = nullptr;
+    size_t bin_capacity = 0;
+    uint32_t bin_key[5] = {0, 0, 0, 0, 0};   // width, height, grid, shard_index, shard_count
     void* temp = nullptr;
     size_t temp_bytes = 0;
     void release() {
-        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp})
+        for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp,
+                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }

@@ -1931,6 +1931,106 @@ __device__ __forceinline__ RasterSetup raster_setup(rt_f3 e1, rt_f3 e2, rt_f3 v0
     return rs;
 }
 
+// One triangle made ready for projection: its data, its object, the box of samples that holds every
+// sample the exact test can accept, and the half-planes.
+struct RasterTri {
+    rt_f3 e1, e2, v0;
+    uint32_t objword;          // object index; bit 31: the object's box test is true for every camera ray
+    int u0, u1, w0, w1;        // empty (u0 > u1) when nothing can be accepted
+    RasterSetup rs;
+};
+__device__ __forceinline__ RasterTri raster_prepare(const SceneView& sv, const DevRenderParams& p, uint32_t id, int gw,
+                                                    int gh, float aspect, uint32_t& st_bytes) {
+    RasterTri rt;
+    uint32_t moi = 0;
+    while (id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
+    const float* t9 = sv.tri9 + 9 * (size_t)id;
+    const rt_f3 me1 = ld3(t9), me2 = ld3(t9 + 3), mv0 = ld3(t9 + 6);
+    st_bytes += 36;
+    rt.e1 = me1, rt.e2 = me2, rt.v0 = mv0;
+    const rt_f3 vb = mv0 + me1, vc = mv0 + me2;
+    int mu0 = 0, mu1 = gw - 1, mw0 = 0, mw1 = gh - 1;
+    const float zmin = fminf(mv0.z, fminf(vb.z, vc.z)), zmax = fmaxf(mv0.z, fmaxf(vb.z, vc.z));
+    // |dx| <= aspect and |dy| <= 1 on the whole sample grid (src/main.rs:322-324).
+    rt.rs = raster_setup(me1, me2, mv0, aspect, 1.0f, zmax * 1.000001f);
+    const DevObject& ob = sv.objs[moi];
+    const float ax = (float)gw * 0.5f / aspect, ay = (float)gh * 0.5f;
+    const float lim = 1.0e9f;
+    if (zmin > 1e-3f && rt.rs.grow < RT_INF) {
+        // Sample column of image-plane x: xx = (2 (x + o) / W - 1) * aspect, sample index
+        // (x + o) * g - 0.5. The hardware reciprocal will do: RT_RASTER_SLOP covers its error and
+        // the rounding of the products many times over.
+        const float ia = __builtin_amdgcn_rcpf(mv0.z), ib = __builtin_amdgcn_rcpf(vb.z), ic = __builtin_amdgcn_rcpf(vc.z);
+        const float xa = mv0.x * ia, xb = vb.x * ib, xc = vc.x * ic;
+        const float ya = mv0.y * ia, yb = vb.y * ib, yc = vc.y * ic;
+        const float fu0 = (fminf(xa, fminf(xb, xc)) + aspect) * ax - 0.5f;
+        const float fu1 = (fmaxf(xa, fmaxf(xb, xc)) + aspect) * ax - 0.5f;
+        const float fw0 = (1.0f - fmaxf(ya, fmaxf(yb, yc))) * ay - 0.5f;
+        const float fw1 = (1.0f - fminf(ya, fminf(yb, yc))) * ay - 0.5f;
+        // The box that holds every sample the exact test can accept: the vertices' box grown by
+        // `grow` of its extent, the slop, and a relative part for sample coordinates in the
+        // tens of thousands.
+        const float mx = (fu1 - fu0) * rt.rs.grow + RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fu0), __builtin_fabsf(fu1));
+        const float my = (fw1 - fw0) * rt.rs.grow + RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fw0), __builtin_fabsf(fw1));
+        mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - mx, -lim), lim)));
+        mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + mx, -lim), lim)));
+        mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - my, -lim), lim)));
+        mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + my, -lim), lim)));
+    }
+    // The reference tests a triangle only for rays that pass the slab test of its leaf: the box of
+    // the eight consecutive triangles it is packed with (src/main.rs:103-111, src/simd_accel.rs:342-377).
+    // With the origin at zero that test is  max_k(min_k * inv_k) <= min_k(max_k * inv_k),  products of
+    // rounded reciprocals: it can only pass for directions inside the projection of the leaf's box
+    // (all of it in front of the camera) widened by a few units of rounding, far inside the slop.
+    // That bounds the samples of a triangle whatever its own shape, edge-on ones included. (The
+    // leftover leaves at the end of an object go through the looser scalar test, src/main.rs:134-136,
+    // and are not bounded this way.)
+    const uint32_t leaf = (id - ob.tri_base) >> 3, n_leaves = ob.n_tris >> 3;
+    if (leaf < (n_leaves & ~7u)) {
+        const float* lb = sv.leaf_bounds + 6 * (size_t)(ob.leaf_base + leaf);
+        const rt_f3 lo = ld3(lb), hi = ld3(lb + 3);
+        st_bytes += 24;
+        if (lo.z > 1e-3f) {
+            const float in = __builtin_amdgcn_rcpf(lo.z), ifar = __builtin_amdgcn_rcpf(hi.z);
+            const float bx0 = lo.x * (lo.x < 0.0f ? in : ifar), bx1 = hi.x * (hi.x > 0.0f ? in : ifar);
+            const float by0 = lo.y * (lo.y < 0.0f ? in : ifar), by1 = hi.y * (hi.y > 0.0f ? in : ifar);
+            const float fu0 = (bx0 + aspect) * ax - 0.5f, fu1 = (bx1 + aspect) * ax - 0.5f;
+            const float fw0 = (1.0f - by1) * ay - 0.5f, fw1 = (1.0f - by0) * ay - 0.5f;
+            const float mx = RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fu0), __builtin_fabsf(fu1));
+            const float my = RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fw0), __builtin_fabsf(fw1));
+            mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - mx, -lim), lim)));
+            mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + mx, -lim), lim)));
+            mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - my, -lim), lim)));
+            mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + my, -lim), lim)));
+        }
+    }
+    if (!rt.rs.visible) mu1 = mu0 - 1;
+    rt.u0 = mu0, rt.u1 = mu1, rt.w0 = mw0, rt.w1 = mw1;
+    // The object's box test (src/main.rs:101, src/objects.rs:322-333) with the origin at zero is
+    // g_min(t_near, 0) <= t_far. When the box holds the view axis on both lateral axes and reaches
+    // in front of the camera, one end of every lateral slab interval is >= 0 whatever the
+    // direction, and so is the far end along z: t_far >= 0, the test is true for every sample.
+    const bool always = ob.bbmin[0] < 0.0f && ob.bbmax[0] > 0.0f && ob.bbmin[1] < 0.0f && ob.bbmax[1] > 0.0f &&
+                        ob.bbmax[2] > 0.0f && ob.bbmin[2] > -RT_INF;
+    rt.objword = moi | (always ? 0x80000000u : 0u);
+    return rt;
+}
+
+// box_intersection_check (src/objects.rs:322-333) for the camera ray of sample column su, row sw
+// against object oi, from the tabulated slab intervals.
+__device__ __forceinline__ bool raster_object_box(const SceneView& sv, const float* __restrict__ tab, uint32_t L, int gw,
+                                                  uint32_t oi, uint32_t su, uint32_t sw) {
+    const DevObject& ob = sv.objs[oi];
+    const float tz1 = (ob.bbmin[2] - 0.0f) * (1.0f / 1.0f), tz2 = (ob.bbmax[2] - 0.0f) * (1.0f / 1.0f);
+    const float nz = g_min(tz1, tz2), fz = g_max(tz1, tz2);
+    const float* near_tab = tab + (size_t)L * (1 + 2 * oi);
+    const float* far_tab = tab + (size_t)L * (2 + 2 * oi);
+    const float nx = near_tab[su], fx = far_tab[su], ny = near_tab[gw + sw], fy = far_tab[gw + sw];
+    const float t_near = g_max(g_max(nx, ny), nz);
+    const float t_far = g_min(g_min(fx, fy), fz);
+    return g_min(t_near, 0.0f) <= t_far;
+}
+
 // Counters of an instrumented run: tri = samples put through the triangle test, box = object box
 // tests, node = blocks of 8 x 8 samples stepped over, bytes = triangle data, table lines and
 // nearest-hit words asked for.
@@ -1942,7 +2042,7 @@ __device__ __forceinline__ RasterSetup raster_setup(rt_f3 e1, rt_f3 e2, rt_f3 v0
 // division, thus runs on full waves of samples that are (nearly all) inside their triangles, instead
 // of on every sample of every box.
 struct RasterLds {
-    float tri[RT_RASTER_TRIS][12];            // e1 xyz, e2 xyz, v0 xyz, id, object, z slab near / far packed below
+    float tri[RT_RASTER_TRIS][12];            // e1 xyz, e2 xyz, v0 xyz, id, object word, -
     float4 queue[RT_RASTER_QUEUE];            // dx, dy, (su | sw << 16), slot
 };
 
@@ -1967,79 +2067,15 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
     rs.grow = 0.0f;
     rs.visible = false;
     if (mine) {
-        uint32_t moi = 0;
-        while (my_id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
-        const float* t9 = sv.tri9 + 9 * (size_t)my_id;
-        const rt_f3 me1 = ld3(t9), me2 = ld3(t9 + 3), mv0 = ld3(t9 + 6);
-        if (STATS) st.bytes += 36;
-        const rt_f3 vb = mv0 + me1, vc = mv0 + me2;
-        mu0 = 0, mu1 = gw - 1, mw0 = 0, mw1 = gh - 1;
-        const float zmin = fminf(mv0.z, fminf(vb.z, vc.z)), zmax = fmaxf(mv0.z, fmaxf(vb.z, vc.z));
-        // |dx| <= aspect and |dy| <= 1 on the whole sample grid (src/main.rs:322-324).
-        rs = raster_setup(me1, me2, mv0, aspect, 1.0f, zmax * 1.000001f);
-        const DevObject& ob = sv.objs[moi];
-        const float ax = (float)gw * 0.5f / aspect, ay = (float)gh * 0.5f;
-        const float lim = 1.0e9f;
-        if (zmin > 1e-3f && rs.grow < RT_INF) {
-            // Sample column of image-plane x: xx = (2 (x + o) / W - 1) * aspect, sample index
-            // (x + o) * g - 0.5. The hardware reciprocal will do: RT_RASTER_SLOP covers its error and
-            // the rounding of the products many times over.
-            const float ia = __builtin_amdgcn_rcpf(mv0.z), ib = __builtin_amdgcn_rcpf(vb.z), ic = __builtin_amdgcn_rcpf(vc.z);
-            const float xa = mv0.x * ia, xb = vb.x * ib, xc = vc.x * ic;
-            const float ya = mv0.y * ia, yb = vb.y * ib, yc = vc.y * ic;
-            const float fu0 = (fminf(xa, fminf(xb, xc)) + aspect) * ax - 0.5f;
-            const float fu1 = (fmaxf(xa, fmaxf(xb, xc)) + aspect) * ax - 0.5f;
-            const float fw0 = (1.0f - fmaxf(ya, fmaxf(yb, yc))) * ay - 0.5f;
-            const float fw1 = (1.0f - fminf(ya, fminf(yb, yc))) * ay - 0.5f;
-            // The box that holds every sample the exact test can accept: the vertices' box grown by
-            // `grow` of its extent, the slop, and a relative part for sample coordinates in the
-            // tens of thousands.
-            const float mx = (fu1 - fu0) * rs.grow + RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fu0), __builtin_fabsf(fu1));
-            const float my = (fw1 - fw0) * rs.grow + RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fw0), __builtin_fabsf(fw1));
-            mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - mx, -lim), lim)));
-            mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + mx, -lim), lim)));
-            mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - my, -lim), lim)));
-            mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + my, -lim), lim)));
-        }
-        // The reference tests a triangle only for rays that pass the slab test of its leaf: the box of
-        // the eight consecutive triangles it is packed with (src/main.rs:103-111, src/simd_accel.rs:342-377).
-        // With the origin at zero that test is  max_k(min_k * inv_k) <= min_k(max_k * inv_k),  products of
-        // rounded reciprocals: it can only pass for directions inside the projection of the leaf's box
-        // (all of it in front of the camera) widened by a few units of rounding, far inside the slop.
-        // That bounds the samples of a triangle whatever its own shape, edge-on ones included. (The
-        // leftover leaves at the end of an object go through the looser scalar test, src/main.rs:134-136,
-        // and are not bounded this way.)
-        const uint32_t leaf = (my_id - ob.tri_base) >> 3, n_leaves = ob.n_tris >> 3;
-        if (leaf < (n_leaves & ~7u)) {
-            const float* lb = sv.leaf_bounds + 6 * (size_t)(ob.leaf_base + leaf);
-            const rt_f3 lo = ld3(lb), hi = ld3(lb + 3);
-            if (STATS) st.bytes += 24;
-            if (lo.z > 1e-3f) {
-                const float in = __builtin_amdgcn_rcpf(lo.z), ifar = __builtin_amdgcn_rcpf(hi.z);
-                const float bx0 = lo.x * (lo.x < 0.0f ? in : ifar), bx1 = hi.x * (hi.x > 0.0f ? in : ifar);
-                const float by0 = lo.y * (lo.y < 0.0f ? in : ifar), by1 = hi.y * (hi.y > 0.0f ? in : ifar);
-                const float fu0 = (bx0 + aspect) * ax - 0.5f, fu1 = (bx1 + aspect) * ax - 0.5f;
-                const float fw0 = (1.0f - by1) * ay - 0.5f, fw1 = (1.0f - by0) * ay - 0.5f;
-                const float mx = RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fu0), __builtin_fabsf(fu1));
-                const float my = RT_RASTER_SLOP + 1e-6f * fmaxf(__builtin_fabsf(fw0), __builtin_fabsf(fw1));
-                mu0 = max(mu0, (int)floorf(fminf(fmaxf(fu0 - mx, -lim), lim)));
-                mu1 = min(mu1, (int)ceilf(fminf(fmaxf(fu1 + mx, -lim), lim)));
-                mw0 = max(mw0, (int)floorf(fminf(fmaxf(fw0 - my, -lim), lim)));
-                mw1 = min(mw1, (int)ceilf(fminf(fmaxf(fw1 + my, -lim), lim)));
-            }
-        }
+        const RasterTri rt = raster_prepare(sv, p, my_id, gw, gh, aspect, st.bytes);
+        rs = rt.rs;
+        mu0 = rt.u0, mu1 = rt.u1, mw0 = rt.w0, mw1 = rt.w1;
         float* td = lds.tri[lane];
-        td[0] = me1.x, td[1] = me1.y, td[2] = me1.z;
-        td[3] = me2.x, td[4] = me2.y, td[5] = me2.z;
-        td[6] = mv0.x, td[7] = mv0.y, td[8] = mv0.z;
+        td[0] = rt.e1.x, td[1] = rt.e1.y, td[2] = rt.e1.z;
+        td[3] = rt.e2.x, td[4] = rt.e2.y, td[5] = rt.e2.z;
+        td[6] = rt.v0.x, td[7] = rt.v0.y, td[8] = rt.v0.z;
         td[9] = __uint_as_float(my_id);
-        // The object's box test (src/main.rs:101, src/objects.rs:322-333) with the origin at zero is
-        // g_min(t_near, 0) <= t_far. When the box holds the view axis on both lateral axes and reaches
-        // in front of the camera, one end of every lateral slab interval is >= 0 whatever the
-        // direction, and so is the far end along z: t_far >= 0, the test is true for every sample.
-        const bool always = ob.bbmin[0] < 0.0f && ob.bbmax[0] > 0.0f && ob.bbmin[1] < 0.0f && ob.bbmax[1] > 0.0f &&
-                            ob.bbmax[2] > 0.0f && ob.bbmin[2] > -RT_INF;
-        td[10] = __uint_as_float(moi | (always ? 0x80000000u : 0u));
+        td[10] = __uint_as_float(rt.objword);
         td[11] = 0.0f;
     }
     __syncthreads();
@@ -2064,18 +2100,8 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
         if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) return;
         const uint32_t su = __float_as_uint(e.z) & 0xFFFFu, sw = __float_as_uint(e.z) >> 16;
         if (!(ow & 0x80000000u)) {
-            // box_intersection_check from the tabulated slab intervals of this sample's column and row.
-            const uint32_t oi = ow;
-            const DevObject& ob = sv.objs[oi];
-            const float tz1 = (ob.bbmin[2] - 0.0f) * (1.0f / 1.0f), tz2 = (ob.bbmax[2] - 0.0f) * (1.0f / 1.0f);
-            const float nz = g_min(tz1, tz2), fz = g_max(tz1, tz2);
-            const float* near_tab = tab + (size_t)L * (1 + 2 * oi);
-            const float* far_tab = tab + (size_t)L * (2 + 2 * oi);
-            const float nx = near_tab[su], fx = far_tab[su], ny = near_tab[gw + sw], fy = far_tab[gw + sw];
             if (STATS) st.box += 1, st.bytes += 16;
-            const float t_near = g_max(g_max(nx, ny), nz);
-            const float t_far = g_min(g_min(fx, fy), fz);
-            if (!(g_min(t_near, 0.0f) <= t_far)) return;
+            if (!raster_object_box(sv, tab, L, gw, ow, su, sw)) return;
         }
         if (STATS) st.bytes += 8;
         const uint32_t x = su >> gs, y = sw >> gs;
@@ -2151,6 +2177,379 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
     if (q_tail != q_head) {
         __syncthreads();
         test_candidates(q_tail - q_head);
+    }
+    if (STATS) flush_stats(st, stats);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projection by screen tile. The kernel above keeps every sample's nearest hit with an atomic
+// minimum in device memory: five layers of triangles make 170 M of them on the benchmark frame, and
+// the words do not stay in L2 between layers. Here the triangles are first put into lists per tile of
+// RT_RTILE x RT_RTILE samples (count, prefix sum, fill: the list of a tile holds every triangle whose
+// box of samples and whose half-planes meet it), and then one wave owns one tile: the nearest-hit
+// words of its 1024 samples live in LDS, the wave goes through the tile's list 64 triangles at a time
+// (one lane sets one triangle up, then the wave steps over the blocks of the triangle's box inside the
+// tile, queues the samples that pass the half-planes and puts 64 of them through the exact test at a
+// time), and at the end writes the samples' records itself: hit point, id, state, light-space key,
+// exactly what k_wf_primary stores. No atomics on device memory, no nearest-hit buffer, no record pass.
+// A tile's 1024 samples are 1024 consecutive record slots (the pixels of a tile are numbered along a
+// Morton curve and the samples of a pixel are consecutive).
+// ---------------------------------------------------------------------------------------------
+#define RT_RTILE 32u
+#define RT_RTILE_TRIS 64   // triangles of a tile's list a wave sets up at a time
+
+// Raster tiles of the frame: ceil(gw / 32) x ceil(gh / 32), numbered row by row.
+__device__ __forceinline__ bool raster_tile_owned(const DevRenderParams& p, uint32_t gs, uint32_t rtx, uint32_t rty) {
+    if (p.shard_count <= 1) return true;
+    const uint32_t ptx = ((rtx * RT_RTILE) >> gs) / RT_TILE, pty = ((rty * RT_RTILE) >> gs) / RT_TILE;
+    return (ptx + pty) % p.shard_count == p.shard_index;
+}
+
+// True when no sample of the rectangle [x0, x1] x [y0, y1] can pass the three half-planes (see the
+// block test in k_raster: the functions are monotone in the table's columns and rows).
+__device__ __forceinline__ bool raster_rect_outside(const RasterSetup& rs, const float* __restrict__ tab, int gw, int x0,
+                                                    int x1, int y0, int y1) {
+    const float dx_lo = tab[x0], dx_hi = tab[x1], dy_hi = tab[gw + y0], dy_lo = tab[gw + y1];
+    const float fu = __builtin_fmaf(rs.gu.x < 0.0f ? dx_lo : dx_hi, rs.gu.x, __builtin_fmaf(rs.gu.y < 0.0f ? dy_lo : dy_hi, rs.gu.y, rs.gu.z));
+    const float fv = __builtin_fmaf(rs.gv.x < 0.0f ? dx_lo : dx_hi, rs.gv.x, __builtin_fmaf(rs.gv.y < 0.0f ? dy_lo : dy_hi, rs.gv.y, rs.gv.z));
+    const float fw = __builtin_fmaf(rs.gw.x < 0.0f ? dx_lo : dx_hi, rs.gw.x, __builtin_fmaf(rs.gw.y < 0.0f ? dy_lo : dy_hi, rs.gw.y, rs.gw.z));
+    return (fu < 0.0f) || (fv < 0.0f) || (fw < 0.0f);
+}
+
+// One lane per triangle. FILL == false: counts[t] += 1 for every tile t the triangle goes to.
+// FILL == true: list[offsets[t] + counts[t]++] = triangle id (counts zeroed in between; `capacity`
+// entries at most are written).
+template <bool FILL>
+__global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_total, const float* __restrict__ tab,
+                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                             uint32_t* __restrict__ list, uint32_t capacity) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = id < n_tris_total;
+    const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g);
+    const float aspect = (float)(p.width / p.height);
+    const int gw = (int)(p.width * g), gh = (int)(p.height * g);
+    uint32_t unused = 0;
+    const RasterTri rt = raster_prepare(sv, p, valid ? id : 0u, gw, gh, aspect, unused);
+    const uint32_t ntx = ((uint32_t)gw + RT_RTILE - 1u) / RT_RTILE;
+    const bool any = valid && rt.u0 <= rt.u1 && rt.w0 <= rt.w1;
+    const uint32_t tx0 = any ? (uint32_t)rt.u0 / RT_RTILE : 1u, tx1 = any ? (uint32_t)rt.u1 / RT_RTILE : 0u;
+    const uint32_t ty0 = any ? (uint32_t)rt.w0 / RT_RTILE : 1u, ty1 = any ? (uint32_t)rt.w1 / RT_RTILE : 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    // A triangle whose box spans many tiles (a large one, or one whose box is only bounded by its
+    // leaf) is walked by the whole wave, one lane per tile, so that no lane holds the others up.
+    const bool big = any && (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) > 8u;
+    unsigned long long bigs = __ballot(big);
+    while (bigs != 0ull) {
+        const int l = __builtin_ctzll(bigs);
+        bigs &= bigs - 1ull;
+        RasterSetup rs;
+        rs.gu = f3(bcast(rt.rs.gu.x, l), bcast(rt.rs.gu.y, l), bcast(rt.rs.gu.z, l));
+        rs.gv = f3(bcast(rt.rs.gv.x, l), bcast(rt.rs.gv.y, l), bcast(rt.rs.gv.z, l));
+        rs.gw = f3(bcast(rt.rs.gw.x, l), bcast(rt.rs.gw.y, l), bcast(rt.rs.gw.z, l));
+        const int u0 = __builtin_amdgcn_readlane(rt.u0, l), u1 = __builtin_amdgcn_readlane(rt.u1, l);
+        const int w0 = __builtin_amdgcn_readlane(rt.w0, l), w1 = __builtin_amdgcn_readlane(rt.w1, l);
+        const uint32_t bid = (uint32_t)__builtin_amdgcn_readlane((int)id, l);
+        const uint32_t bx0 = (uint32_t)u0 / RT_RTILE, nx = (uint32_t)u1 / RT_RTILE - bx0 + 1u;
+        const uint32_t by0 = (uint32_t)w0 / RT_RTILE, ny = (uint32_t)w1 / RT_RTILE - by0 + 1u;
+        for (uint32_t k = lane; k < nx * ny; k += 64u) {
+            const uint32_t tyk = by0 + k / nx, txk = bx0 + k % nx;
+            if (!raster_tile_owned(p, gs, txk, tyk)) continue;
+            const int x0 = max(u0, (int)(txk * RT_RTILE)), x1 = min(u1, (int)(txk * RT_RTILE + RT_RTILE - 1u));
+            const int y0 = max(w0, (int)(tyk * RT_RTILE)), y1 = min(w1, (int)(tyk * RT_RTILE + RT_RTILE - 1u));
+            if (raster_rect_outside(rs, tab, gw, x0, x1, y0, y1)) continue;
+            const uint32_t t = tyk * ntx + txk;
+            const uint32_t pos = atomicAdd(&counts[t], 1u);
+            if (FILL && offsets[t] + pos < capacity) list[offsets[t] + pos] = bid;
+        }
+    }
+    // The other lanes walk their own triangles' tiles; the wave keeps turning until all are through.
+    // Neighbouring triangles go to the same few tiles, so the lanes that name one tile in a turn add
+    // to its counter together: one atomic per distinct tile and turn instead of one per lane.
+    uint32_t tx = tx0, ty = ty0;
+    bool walking = any && !big;
+    while (__ballot(walking) != 0ull) {
+        bool want = false;
+        uint32_t t = 0xFFFFFFFFu;
+        if (walking) {
+            if (raster_tile_owned(p, gs, tx, ty)) {
+                const int x0 = max(rt.u0, (int)(tx * RT_RTILE)), x1 = min(rt.u1, (int)(tx * RT_RTILE + RT_RTILE - 1u));
+                const int y0 = max(rt.w0, (int)(ty * RT_RTILE)), y1 = min(rt.w1, (int)(ty * RT_RTILE + RT_RTILE - 1u));
+                want = !raster_rect_outside(rt.rs, tab, gw, x0, x1, y0, y1);
+                t = ty * ntx + tx;
+            }
+            if (++tx > tx1) {
+                tx = tx0;
+                walking = ++ty <= ty1;
+            }
+        }
+        unsigned long long todo = __ballot(want);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
+            const unsigned long long peers = __ballot(want && t == tl);
+            todo &= ~peers;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&counts[tl], (uint32_t)__builtin_popcountll(peers));
+            if (FILL) {
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                if (want && t == tl) {
+                    const uint32_t pos = offsets[tl] + base +
+                                         (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
+                    if (pos < capacity) list[pos] = id;
+                }
+            }
+        }
+    }
+}
+
+// offsets[i] = counts[0] + ... + counts[i - 1] for i = 0 .. n (offsets[n] = the total); counts are
+// set to zero. One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0;   // sum of everything before the current stretch of 4096 counters
+    for (uint32_t first = 0; first < n; first += 4096u) {
+        const uint32_t i = first + 4u * t;
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = i + k < n ? counts[i + k] : 0u;
+            if (i + k < n) counts[i + k] = 0u;
+        }
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = mine;   // inclusive sum over the wave's lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += v;
+        }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry, total = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t v = s_wave[w];
+            if (w < wave) before += v;
+            total += v;
+        }
+        uint32_t run = before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < n) offsets[i + k] = run;
+            run += c[k];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (t == 0) offsets[n] = carry;
+}
+
+struct RasterTileLds {
+    unsigned long long z[RT_RTILE * RT_RTILE];   // nearest (t, id) per sample of the tile, row by row
+    float tri[RT_RTILE_TRIS][12];                // e1 xyz, e2 xyz, v0 xyz, id, object word, -
+    uint32_t queue[RT_RASTER_QUEUE];             // runs of candidate samples: first sample | length << 10 | slot << 16
+    float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
+};
+#define RT_RUN 4u   // samples per queued run: a wave tests 16 runs at a time
+
+// Position (subx, suby) of sub-sample s on the n x n grid inside a pixel: the inverse of sample_of.
+__device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t s, uint32_t* subx, uint32_t* suby) {
+    if (grid == 2) {
+        *subx = s & 1u;
+        *suby = (s == 1u || s == 2u) ? 1u : 0u;
+    } else {
+        *subx = s % grid;
+        *suby = s / grid;
+    }
+}
+
+// One half-plane along one row of the tile, F(column) = fma(dx[column], gx, r): the columns that
+// pass (!(F < 0)) are those at or beyond the boundary x = (aspect - r / gx) * ax - 0.5 for gx > 0, at
+// or before it for gx < 0. fma is correctly rounded, so the sign of F is the sign of the exact
+// dx * gx + r; the table's dx differs from (column + 0.5) / ax - aspect by a few units of its
+// last place, a few thousandths of a column, and so does `x` (computed with a rounded reciprocal)
+// from the exact boundary unless it lies far outside the tile. Cutting at floor(x) below and
+// ceil(x) above therefore keeps every passing column (and at most one more each side). An x that is
+// NaN (gx == 0 with r == 0) cuts nothing.
+__device__ __forceinline__ void row_clip(float gx, float x, int& lo, int& hi) {
+    if (gx > 0.0f) {
+        const float f = floorf(x);
+        if (f > (float)lo) lo = f <= (float)hi ? (int)f : hi + 1;
+    } else if (gx < 0.0f) {
+        const float c = ceilf(x);
+        if (c < (float)hi) hi = c >= (float)lo ? (int)c : lo - 1;
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderParams p, LightProj lp,
+                                                       const uint32_t* __restrict__ tile_list,
+                                                       const float* __restrict__ tab,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ list,
+                                                       float4* __restrict__ samp, uint32_t* __restrict__ state,
+                                                       uint32_t* __restrict__ keys, DevStats* __restrict__ stats) {
+    __shared__ RasterTileLds lds;
+    LaneStats st;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g), spp = p.spp;
+    const float aspect = (float)(p.width / p.height);
+    const int gw = (int)(p.width * g), gh = (int)(p.height * g);
+    const uint32_t L = (uint32_t)(gw + gh);
+    // Which raster tile: sub-tile (a, b) of g x g in pixel tile `launch_tile` of this launch.
+    const uint32_t launch_tile = blockIdx.x / spp, sub = blockIdx.x % spp;
+    const uint32_t a = sub % g, b = sub / g;
+    const uint32_t local_tile = p.tile_first + launch_tile;
+    const uint32_t tile = tile_list ? tile_list[local_tile] : local_tile;
+    const uint32_t ptx = tile % p.tiles_x, pty = tile / p.tiles_x;
+    const uint32_t rtx = ptx * g + a, rty = pty * g + b;
+    const int su0 = (int)(rtx * RT_RTILE), sw0 = (int)(rty * RT_RTILE);
+    const uint32_t P = RT_RTILE >> gs;                       // pixels a side of this raster tile
+    // Morton number of the raster tile's first pixel inside its pixel tile.
+    uint32_t m0 = 0;
+    {
+        const uint32_t px0 = a * P, py0 = b * P;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) m0 |= (((px0 >> k) & 1u) << (2 * k)) | (((py0 >> k) & 1u) << (2 * k + 1));
+    }
+    const uint32_t slot_base = launch_tile * (RT_TILE * RT_TILE * spp) + m0 * spp;
+    const uint32_t ntx = ((uint32_t)gw + RT_RTILE - 1u) / RT_RTILE;
+    const bool on_frame = su0 < gw && sw0 < gh;
+
+    for (uint32_t i = lane; i < RT_RTILE * RT_RTILE; i += 64u) lds.z[i] = RT_ZKEY_NONE;
+    if (lane < RT_RTILE) lds.dx[lane] = tab[min(su0 + (int)lane, gw - 1)];
+    else lds.dy[lane - RT_RTILE] = tab[gw + min(sw0 + (int)(lane - RT_RTILE), gh - 1)];
+    __syncthreads();
+
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform: runs wait at queue[(q_head .. q_tail) % RT_RASTER_QUEUE]
+    const rt_f3 o = f3(0.0f, 0.0f, 0.0f);
+    // Puts the samples of up to 16 waiting runs through the exact test: the reference's arithmetic on
+    // the reference's ray, acceptance rule !failed && t > 0 (src/main.rs:117), then the object's box
+    // test; the nearest (t, id) of a sample is kept with an atomic minimum in LDS.
+    auto test_runs = [&](uint32_t n) {
+        const uint32_t e = lds.queue[(q_head + min(lane / RT_RUN, n - 1u)) % RT_RASTER_QUEUE];
+        q_head += n;
+        const uint32_t j = lane % RT_RUN;
+        if (lane / RT_RUN >= n || j >= ((e >> 10) & 7u)) return;
+        const uint32_t zi = (e & 1023u) + j;
+        const float* td = lds.tri[e >> 16];
+        const rt_f3 e1 = f3(td[0], td[1], td[2]), e2 = f3(td[3], td[4], td[5]), v0 = f3(td[6], td[7], td[8]);
+        const uint32_t id = __float_as_uint(td[9]), ow = __float_as_uint(td[10]);
+        const rt_f3 d = f3(lds.dx[zi & (RT_RTILE - 1u)], lds.dy[zi / RT_RTILE], 1.0f);
+        if (STATS) st.tri += 1;
+        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+        if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) return;
+        if (!(ow & 0x80000000u)) {
+            if (STATS) st.box += 1, st.bytes += 16;
+            if (!raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + (zi & (RT_RTILE - 1u)), (uint32_t)sw0 + zi / RT_RTILE)) return;
+        }
+        atomicMin(&lds.z[zi], ((unsigned long long)__float_as_uint(ev.t) << 32) | id);
+    };
+
+    const uint32_t rt_index = rty * ntx + rtx;
+    const uint32_t first = on_frame ? offsets[rt_index] : 0u, n_list = on_frame ? offsets[rt_index + 1] - first : 0u;
+    // Column of image-plane x: dx = (column + 0.5) / ax - aspect up to rounding, so a half-plane's
+    // boundary along a row, fma(dx, gx, r) = 0, lies near column (aspect - r / gx) * ax - 0.5.
+    const float ax = (float)gw * 0.5f / aspect;
+    for (uint32_t base = 0; base < n_list; base += RT_RTILE_TRIS) {
+        // One lane sets one triangle of the list up; its box is cut to the tile (tile-local from here on).
+        int c0 = 0, c1 = -1, r0 = 0, r1 = -1;
+        RasterSetup rs;
+        rs.gu = rs.gv = rs.gw = f3(0.0f, 0.0f, 0.0f);
+        if (base + lane < n_list) {
+            const uint32_t id = list[first + base + lane];
+            if (STATS) st.bytes += 4;
+            const RasterTri rt = raster_prepare(sv, p, id, gw, gh, aspect, st.bytes);
+            rs = rt.rs;
+            c0 = max(rt.u0 - su0, 0), c1 = min(rt.u1 - su0, (int)RT_RTILE - 1);
+            r0 = max(rt.w0 - sw0, 0), r1 = min(rt.w1 - sw0, (int)RT_RTILE - 1);
+            if (c0 > c1) r1 = r0 - 1;
+            float* td = lds.tri[lane];
+            td[0] = rt.e1.x, td[1] = rt.e1.y, td[2] = rt.e1.z;
+            td[3] = rt.e2.x, td[4] = rt.e2.y, td[5] = rt.e2.z;
+            td[6] = rt.v0.x, td[7] = rt.v0.y, td[8] = rt.v0.z;
+            td[9] = __uint_as_float(id);
+            td[10] = __uint_as_float(rt.objword);
+        }
+        // slope and offset of the boundary column as a function of the row's r = fma(dy, gy, gz)
+        const float off = (aspect * ax - 0.5f) - (float)su0;
+        const float ku = -ax * __builtin_amdgcn_rcpf(rs.gu.x), kv = -ax * __builtin_amdgcn_rcpf(rs.gv.x),
+                    kw = -ax * __builtin_amdgcn_rcpf(rs.gw.x);
+        __syncthreads();
+        // Every lane goes down the rows of its own triangle: per row, the run of columns that pass
+        // all three half-planes (an exact run: see row_clip), queued in pieces of RT_RUN samples.
+        for (int row = r0; __ballot(row <= r1) != 0ull; ++row) {
+            int lo = c0, hi = row <= r1 ? c1 : c0 - 1;
+            if (lo <= hi) {
+                if (STATS) st.node += 1;
+                const float dy = lds.dy[row];
+                const float ru = __builtin_fmaf(dy, rs.gu.y, rs.gu.z), rv = __builtin_fmaf(dy, rs.gv.y, rs.gv.z),
+                            rw = __builtin_fmaf(dy, rs.gw.y, rs.gw.z);
+                row_clip(rs.gu.x, __builtin_fmaf(ru, ku, off), lo, hi);
+                row_clip(rs.gv.x, __builtin_fmaf(rv, kv, off), lo, hi);
+                row_clip(rs.gw.x, __builtin_fmaf(rw, kw, off), lo, hi);
+                // a half-plane that does not depend on the column passes the whole row or none of it
+                if ((rs.gu.x == 0.0f && ru < 0.0f) || (rs.gv.x == 0.0f && rv < 0.0f) || (rs.gw.x == 0.0f && rw < 0.0f)) hi = lo - 1;
+            }
+            while (true) {
+                const bool has = lo <= hi;
+                const unsigned long long pm = __ballot(has);
+                if (pm == 0ull) break;
+                if (has) {
+                    const uint32_t len = min((uint32_t)(hi - lo + 1), RT_RUN);
+                    const uint32_t pos = q_tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                    lds.queue[pos % RT_RASTER_QUEUE] = ((uint32_t)row * RT_RTILE + (uint32_t)lo) | (len << 10) | (lane << 16);
+                    lo += (int)RT_RUN;
+                }
+                q_tail += (uint32_t)__builtin_popcountll(pm);
+                if (q_tail - q_head >= 64u) {
+                    __syncthreads();
+                    while (q_tail - q_head >= 16u) test_runs(16u);
+                    __syncthreads();
+                }
+            }
+        }
+        // The triangle slots are reused by the next 64 triangles: test what still waits.
+        __syncthreads();
+        while (q_tail != q_head) test_runs(min(q_tail - q_head, 16u));
+        __syncthreads();
+    }
+
+    // The records of the tile's samples, in slot order: what k_wf_primary stores.
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    for (uint32_t k = lane; k < RT_RTILE * RT_RTILE; k += 64u) {
+        const uint32_t pl = k / spp, s = k % spp;      // pixel of the raster tile (Morton number), sample
+        uint32_t pxl = 0, pyl = 0;
+#pragma unroll
+        for (int bit = 0; bit < 5; ++bit) {
+            pxl |= ((pl >> (2 * bit)) & 1u) << bit;
+            pyl |= ((pl >> (2 * bit + 1)) & 1u) << bit;
+        }
+        uint32_t subx, suby;
+        sample_pos(g, s, &subx, &suby);
+        const uint32_t sul = pxl * g + subx, swl = pyl * g + suby;   // sample inside the tile
+        const uint32_t x = ((uint32_t)su0 + sul) >> gs, y = ((uint32_t)sw0 + swl) >> gs;
+        const bool inside = x < p.width && y < p.height;
+#ifdef RT_EXP_NO_FINAL
+        const unsigned long long key = RT_ZKEY_NONE;
+#else
+        const unsigned long long key = inside ? lds.z[swl * RT_RTILE + sul] : RT_ZKEY_NONE;
+#endif
+        const bool hit_any = key != RT_ZKEY_NONE;
+        HitD hs;
+        hs.tri = hit_any ? (uint32_t)key : 0u;
+        hs.t = hit_any ? __uint_as_float((uint32_t)(key >> 32)) : 0.0f;
+        hs.u = hs.v = 0.0f;
+        hs.obj = 0;
+        while (hs.obj + 1 < sv.n_objs && hs.tri >= sv.objs[hs.obj].tri_base + sv.objs[hs.obj].n_tris) ++hs.obj;
+        const rt_f3 d = f3(lds.dx[sul], lds.dy[swl], 1.0f);
+        const Surface sf = surface_of(sv, hs, o, d);
+        const rt_f3 sun_dir = g_normalize(sun - sf.pos);
+        const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
+        const uint32_t slot = slot_base + k;
+        samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(hit_any ? hs.tri : RT_MISS));
+        state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
+        keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
+        if (STATS) st.rays += inside ? 1u : 0u;
     }
     if (STATS) flush_stats(st, stats);
 }
@@ -2685,6 +3084,38 @@ hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t 
     const dim3 grid((n_tris_total + RT_RASTER_TRIS - 1) / RT_RASTER_TRIS);
     if (d_stats) hipLaunchKernelGGL(k_raster<true>, grid, dim3(64), 0, s, sv, p, n_tris_total, d_table, d_zbuf, d_stats);
     else hipLaunchKernelGGL(k_raster<false>, grid, dim3(64), 0, s, sv, p, n_tris_total, d_table, d_zbuf, d_stats);
+    return hipGetLastError();
+}
+
+hipError_t raster_bin(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
+                      uint32_t n_raster_tiles, uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_list, uint32_t capacity,
+                      bool fill, hipStream_t s) {
+    if (n_tris_total == 0) return hipSuccess;
+    const dim3 grid((n_tris_total + 255u) / 256u);
+    if (!fill) {
+        const uint32_t lines = (p.width + p.height) * p.grid;
+        hipLaunchKernelGGL(k_camera_table, dim3((lines + 255) / 256), dim3(256), 0, s, sv, p, d_table);
+        hipError_t e = hipMemsetAsync(d_counts, 0, (size_t)n_raster_tiles * 4, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_raster_bin<false>, grid, dim3(256), 0, s, sv, p, n_tris_total, d_table, d_counts, d_offsets, d_list, capacity);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, d_counts, n_raster_tiles, d_offsets);
+    } else {
+        hipLaunchKernelGGL(k_raster_bin<true>, grid, dim3(256), 0, s, sv, p, n_tris_total, d_table, d_counts, d_offsets, d_list, capacity);
+    }
+    return hipGetLastError();
+}
+
+hipError_t raster_tiles(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
+                        const float* d_table, const uint32_t* d_offsets, const uint32_t* d_list, float4* d_samp,
+                        uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s) {
+    const uint32_t waves = p.n_tiles * p.spp;   // g x g raster tiles of 32 x 32 samples per tile of 32 x 32 pixels
+    if (waves == 0) return hipSuccess;
+    if (d_stats)
+        hipLaunchKernelGGL(k_raster_tile<true>, dim3(waves), dim3(64), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
+                           d_samp, d_state, d_keys, d_stats);
+    else
+        hipLaunchKernelGGL(k_raster_tile<false>, dim3(waves), dim3(64), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
+                           d_samp, d_state, d_keys, d_stats);
     return hipGetLastError();
 }
 

@@ -10,5 +10,5 @@ echo "pytest rc=$?"; tail -4 "$out/pytest.log"
 python3 -c "
 import json,sys
 d=json.loads(open('$out/bench.json').read().strip().splitlines()[-1])
-print(round(d['value']), round(d['ms_per_step'],3), {k: round(v,3) for k,v in d['config']['phase_ms'].items()})"
-python3 "$root/tools/stats_read.py" "$out/stats" 2>/dev/null | grep -v "true" | sed -n 1,9p
+print(round(d['value']), round(d['ms_per_step'],3), {k: round(v,3) for k,v in d['config']['phase_ms'].items()}, d['config'].get('camera_phase_counters'))"
+python3 "$root/tools/stats_read.py" "$out/stats" 2>/dev/null | grep -v "Lb1E\|<true" | sed -n 1,12p
