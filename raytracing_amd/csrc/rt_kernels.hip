@@ -2107,11 +2107,7 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
         const uint32_t x = su >> gs, y = sw >> gs;
         const uint32_t smp = sample_of(g, su & (g - 1u), sw & (g - 1u));
         const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
-#ifdef RT_EXPERIMENT_PLAIN_STORE   // timing experiment only: wrong results
-        zbuf[((size_t)y * p.width + x) * p.spp + smp] = key;
-#else
         atomicMin(&zbuf[((size_t)y * p.width + x) * p.spp + smp], key);
-#endif
     };
 
     while (todo) {
@@ -2196,7 +2192,9 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
 // Morton curve and the samples of a pixel are consecutive).
 // ---------------------------------------------------------------------------------------------
 #define RT_RTILE 32u
+#ifndef RT_RTILE_TRIS
 #define RT_RTILE_TRIS 64   // triangles of a tile's list a wave sets up at a time
+#endif
 
 // Raster tiles of the frame: ceil(gw / 32) x ceil(gh / 32), numbered row by row.
 __device__ __forceinline__ bool raster_tile_owned(const DevRenderParams& p, uint32_t gs, uint32_t rtx, uint32_t rty) {
@@ -2343,13 +2341,28 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ coun
     if (t == 0) offsets[n] = carry;
 }
 
+// Waves that share a tile (each takes every other stretch of the tile's list). Two waves a tile
+// raise the occupancy from 3 to 5 waves a SIMD and measured the same frame time; one is simpler.
+#ifndef RT_RTILE_GROUP
+#define RT_RTILE_GROUP 1
+#endif
 struct RasterTileLds {
     unsigned long long z[RT_RTILE * RT_RTILE];   // nearest (t, id) per sample of the tile, row by row
-    float tri[RT_RTILE_TRIS][12];                // e1 xyz, e2 xyz, v0 xyz, id, object word, -
-    uint32_t queue[RT_RASTER_QUEUE];             // runs of candidate samples: first sample | length << 10 | slot << 16
+    float tri[RT_RTILE_GROUP][RT_RTILE_TRIS][12];    // per wave: e1 xyz, e2 xyz, v0 xyz, id, object word, -
+    uint32_t queue[RT_RTILE_GROUP][RT_RASTER_QUEUE]; // per wave: runs of candidate samples: first sample | length << 10 | slot << 16
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
 };
-#define RT_RUN 4u   // samples per queued run: a wave tests 16 runs at a time
+// Orders a wave's own LDS writes before its later LDS reads (the hardware serves one wave's LDS
+// instructions in order; this keeps the compiler from moving them).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifndef RT_RUN
+#define RT_RUN 8u   // samples per queued run: a wave tests 64 / RT_RUN runs at a time
+#endif
+#define RT_RUNS_PER_TEST (64u / RT_RUN)
 
 // Position (subx, suby) of sub-sample s on the n x n grid inside a pixel: the inverse of sample_of.
 __device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t s, uint32_t* subx, uint32_t* suby) {
@@ -2365,23 +2378,27 @@ __device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t s, uint32_t* 
 // One half-plane along one row of the tile, F(column) = fma(dx[column], gx, r): the columns that
 // pass (!(F < 0)) are those at or beyond the boundary x = (aspect - r / gx) * ax - 0.5 for gx > 0, at
 // or before it for gx < 0. fma is correctly rounded, so the sign of F is the sign of the exact
-// dx * gx + r; the table's dx differs from (column + 0.5) / ax - aspect by a few units of its
-// last place, a few thousandths of a column, and so does `x` (computed with a rounded reciprocal)
-// from the exact boundary unless it lies far outside the tile. Cutting at floor(x) below and
-// ceil(x) above therefore keeps every passing column (and at most one more each side). An x that is
-// NaN (gx == 0 with r == 0) cuts nothing.
+// dx * gx + r; the table's dx differs from (column + 0.5) / ax - aspect by a few units of its last
+// place (under 0.008 column for the widest frames the projection takes, 65535 sample columns), and
+// `x`, computed with a rounded reciprocal, from the exact boundary by as much again unless it
+// lies far outside the tile. With RT_CLIP_SLACK = 1/16 column on either side the cut keeps every
+// passing column. An x that is NaN (gx == 0 with r == 0) cuts nothing.
+#define RT_CLIP_SLACK 0.0625f
 __device__ __forceinline__ void row_clip(float gx, float x, int& lo, int& hi) {
     if (gx > 0.0f) {
-        const float f = floorf(x);
+        const float f = ceilf(x - RT_CLIP_SLACK);
         if (f > (float)lo) lo = f <= (float)hi ? (int)f : hi + 1;
     } else if (gx < 0.0f) {
-        const float c = ceilf(x);
+        const float c = floorf(x + RT_CLIP_SLACK);
         if (c < (float)hi) hi = c >= (float)lo ? (int)c : lo - 1;
     }
 }
 
+#ifndef RT_RTILE_WAVES
+#define RT_RTILE_WAVES 3
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderParams p, LightProj lp,
+__global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_tile(SceneView sv, DevRenderParams p, LightProj lp,
                                                        const uint32_t* __restrict__ tile_list,
                                                        const float* __restrict__ tab,
                                                        const uint32_t* __restrict__ offsets,
@@ -2390,7 +2407,7 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
                                                        uint32_t* __restrict__ keys, DevStats* __restrict__ stats) {
     __shared__ RasterTileLds lds;
     LaneStats st;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g), spp = p.spp;
     const float aspect = (float)(p.width / p.height);
     const int gw = (int)(p.width * g), gh = (int)(p.height * g);
@@ -2415,9 +2432,9 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
     const uint32_t ntx = ((uint32_t)gw + RT_RTILE - 1u) / RT_RTILE;
     const bool on_frame = su0 < gw && sw0 < gh;
 
-    for (uint32_t i = lane; i < RT_RTILE * RT_RTILE; i += 64u) lds.z[i] = RT_ZKEY_NONE;
-    if (lane < RT_RTILE) lds.dx[lane] = tab[min(su0 + (int)lane, gw - 1)];
-    else lds.dy[lane - RT_RTILE] = tab[gw + min(sw0 + (int)(lane - RT_RTILE), gh - 1)];
+    for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE; i += 64u * RT_RTILE_GROUP) lds.z[i] = RT_ZKEY_NONE;
+    if (threadIdx.x < RT_RTILE) lds.dx[threadIdx.x] = tab[min(su0 + (int)threadIdx.x, gw - 1)];
+    else if (threadIdx.x < 2u * RT_RTILE) lds.dy[threadIdx.x - RT_RTILE] = tab[gw + min(sw0 + (int)(threadIdx.x - RT_RTILE), gh - 1)];
     __syncthreads();
 
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform: runs wait at queue[(q_head .. q_tail) % RT_RASTER_QUEUE]
@@ -2426,12 +2443,12 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
     // the reference's ray, acceptance rule !failed && t > 0 (src/main.rs:117), then the object's box
     // test; the nearest (t, id) of a sample is kept with an atomic minimum in LDS.
     auto test_runs = [&](uint32_t n) {
-        const uint32_t e = lds.queue[(q_head + min(lane / RT_RUN, n - 1u)) % RT_RASTER_QUEUE];
+        const uint32_t e = lds.queue[wv][(q_head + min(lane / RT_RUN, n - 1u)) % RT_RASTER_QUEUE];
         q_head += n;
         const uint32_t j = lane % RT_RUN;
-        if (lane / RT_RUN >= n || j >= ((e >> 10) & 7u)) return;
+        if (lane / RT_RUN >= n || j >= ((e >> 10) & 63u)) return;
         const uint32_t zi = (e & 1023u) + j;
-        const float* td = lds.tri[e >> 16];
+        const float* td = lds.tri[wv][e >> 16];
         const rt_f3 e1 = f3(td[0], td[1], td[2]), e2 = f3(td[3], td[4], td[5]), v0 = f3(td[6], td[7], td[8]);
         const uint32_t id = __float_as_uint(td[9]), ow = __float_as_uint(td[10]);
         const rt_f3 d = f3(lds.dx[zi & (RT_RTILE - 1u)], lds.dy[zi / RT_RTILE], 1.0f);
@@ -2450,12 +2467,12 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
     // Column of image-plane x: dx = (column + 0.5) / ax - aspect up to rounding, so a half-plane's
     // boundary along a row, fma(dx, gx, r) = 0, lies near column (aspect - r / gx) * ax - 0.5.
     const float ax = (float)gw * 0.5f / aspect;
-    for (uint32_t base = 0; base < n_list; base += RT_RTILE_TRIS) {
+    for (uint32_t base = wv * RT_RTILE_TRIS; base < n_list; base += RT_RTILE_TRIS * RT_RTILE_GROUP) {
         // One lane sets one triangle of the list up; its box is cut to the tile (tile-local from here on).
         int c0 = 0, c1 = -1, r0 = 0, r1 = -1;
         RasterSetup rs;
         rs.gu = rs.gv = rs.gw = f3(0.0f, 0.0f, 0.0f);
-        if (base + lane < n_list) {
+        if (lane < RT_RTILE_TRIS && base + lane < n_list) {
             const uint32_t id = list[first + base + lane];
             if (STATS) st.bytes += 4;
             const RasterTri rt = raster_prepare(sv, p, id, gw, gh, aspect, st.bytes);
@@ -2463,7 +2480,7 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
             c0 = max(rt.u0 - su0, 0), c1 = min(rt.u1 - su0, (int)RT_RTILE - 1);
             r0 = max(rt.w0 - sw0, 0), r1 = min(rt.w1 - sw0, (int)RT_RTILE - 1);
             if (c0 > c1) r1 = r0 - 1;
-            float* td = lds.tri[lane];
+            float* td = lds.tri[wv][lane];
             td[0] = rt.e1.x, td[1] = rt.e1.y, td[2] = rt.e1.z;
             td[3] = rt.e2.x, td[4] = rt.e2.y, td[5] = rt.e2.z;
             td[6] = rt.v0.x, td[7] = rt.v0.y, td[8] = rt.v0.z;
@@ -2474,7 +2491,7 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
         const float off = (aspect * ax - 0.5f) - (float)su0;
         const float ku = -ax * __builtin_amdgcn_rcpf(rs.gu.x), kv = -ax * __builtin_amdgcn_rcpf(rs.gv.x),
                     kw = -ax * __builtin_amdgcn_rcpf(rs.gw.x);
-        __syncthreads();
+        wave_lds_sync();
         // Every lane goes down the rows of its own triangle: per row, the run of columns that pass
         // all three half-planes (an exact run: see row_clip), queued in pieces of RT_RUN samples.
         for (int row = r0; __ballot(row <= r1) != 0ull; ++row) {
@@ -2497,26 +2514,27 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
                 if (has) {
                     const uint32_t len = min((uint32_t)(hi - lo + 1), RT_RUN);
                     const uint32_t pos = q_tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                    lds.queue[pos % RT_RASTER_QUEUE] = ((uint32_t)row * RT_RTILE + (uint32_t)lo) | (len << 10) | (lane << 16);
+                    lds.queue[wv][pos % RT_RASTER_QUEUE] = ((uint32_t)row * RT_RTILE + (uint32_t)lo) | (len << 10) | (lane << 16);
                     lo += (int)RT_RUN;
                 }
                 q_tail += (uint32_t)__builtin_popcountll(pm);
                 if (q_tail - q_head >= 64u) {
-                    __syncthreads();
-                    while (q_tail - q_head >= 16u) test_runs(16u);
-                    __syncthreads();
+                    wave_lds_sync();
+                    while (q_tail - q_head >= RT_RUNS_PER_TEST) test_runs(RT_RUNS_PER_TEST);
+                    wave_lds_sync();
                 }
             }
         }
         // The triangle slots are reused by the next 64 triangles: test what still waits.
-        __syncthreads();
-        while (q_tail != q_head) test_runs(min(q_tail - q_head, 16u));
-        __syncthreads();
+        wave_lds_sync();
+        while (q_tail != q_head) test_runs(min(q_tail - q_head, RT_RUNS_PER_TEST));
+        wave_lds_sync();
     }
 
+    __syncthreads();   // both waves' nearest hits are in
     // The records of the tile's samples, in slot order: what k_wf_primary stores.
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-    for (uint32_t k = lane; k < RT_RTILE * RT_RTILE; k += 64u) {
+    for (uint32_t k = threadIdx.x; k < RT_RTILE * RT_RTILE; k += 64u * RT_RTILE_GROUP) {
         const uint32_t pl = k / spp, s = k % spp;      // pixel of the raster tile (Morton number), sample
         uint32_t pxl = 0, pyl = 0;
 #pragma unroll
@@ -2529,11 +2547,7 @@ __global__ __launch_bounds__(64, 3) void k_raster_tile(SceneView sv, DevRenderPa
         const uint32_t sul = pxl * g + subx, swl = pyl * g + suby;   // sample inside the tile
         const uint32_t x = ((uint32_t)su0 + sul) >> gs, y = ((uint32_t)sw0 + swl) >> gs;
         const bool inside = x < p.width && y < p.height;
-#ifdef RT_EXP_NO_FINAL
-        const unsigned long long key = RT_ZKEY_NONE;
-#else
         const unsigned long long key = inside ? lds.z[swl * RT_RTILE + sul] : RT_ZKEY_NONE;
-#endif
         const bool hit_any = key != RT_ZKEY_NONE;
         HitD hs;
         hs.tri = hit_any ? (uint32_t)key : 0u;
@@ -3111,10 +3125,10 @@ hipError_t raster_tiles(const SceneView& sv, const DevRenderParams& p, const Lig
     const uint32_t waves = p.n_tiles * p.spp;   // g x g raster tiles of 32 x 32 samples per tile of 32 x 32 pixels
     if (waves == 0) return hipSuccess;
     if (d_stats)
-        hipLaunchKernelGGL(k_raster_tile<true>, dim3(waves), dim3(64), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
+        hipLaunchKernelGGL(k_raster_tile<true>, dim3(waves), dim3(64 * RT_RTILE_GROUP), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
                            d_samp, d_state, d_keys, d_stats);
     else
-        hipLaunchKernelGGL(k_raster_tile<false>, dim3(waves), dim3(64), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
+        hipLaunchKernelGGL(k_raster_tile<false>, dim3(waves), dim3(64 * RT_RTILE_GROUP), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
                            d_samp, d_state, d_keys, d_stats);
     return hipGetLastError();
 }

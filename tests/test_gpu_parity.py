@@ -344,6 +344,11 @@ def test_camera_rays_by_projection_equal_the_beam_walk(soup_pair, monkeypatch, s
     for r in range(3):
         acc |= g.render(render_params(W, H, grid, shard_index=r, shard_count=3, **kw))
     assert np.array_equal(acc, rgba)
+    # the older form of the projection (one nearest-hit word per sample in device memory, atomic minima)
+    monkeypatch.setenv("RAYS_HIP_RASTER", "atomic")
+    assert _stats(g, p)["camera_by_projection"] == 1
+    rgba_at, ids_at = g.render(p, want_hit_ids=True)
+    assert np.array_equal(ids_at, ids) and np.array_equal(rgba_at, rgba)
     monkeypatch.setenv("RAYS_HIP_RASTER", "0")
     assert _stats(g, p)["camera_by_projection"] == 0
     rgba_walk, ids_walk = g.render(p, want_hit_ids=True)
