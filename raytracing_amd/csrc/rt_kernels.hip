@@ -2280,21 +2280,21 @@ __global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_to
                 walking = ++ty <= ty1;
             }
         }
-        unsigned long long todo = __ballot(want);
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
-            const unsigned long long peers = __ballot(want && t == tl);
-            todo &= ~peers;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&counts[tl], (uint32_t)__builtin_popcountll(peers));
-            if (FILL) {
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                if (want && t == tl) {
-                    const uint32_t pos = offsets[tl] + base +
-                                         (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
-                    if (pos < capacity) list[pos] = id;
-                }
+        if (FILL) {
+            // Every lane takes its own place in its tile's list: 64 returning atomics in flight
+            // together are faster than one per distinct tile waited for in turn.
+            if (want) {
+                const uint32_t pos = offsets[t] + atomicAdd(&counts[t], 1u);
+                if (pos < capacity) list[pos] = id;
+            }
+        } else {
+            unsigned long long todo = __ballot(want);
+            while (todo != 0ull) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
+                const unsigned long long peers = __ballot(want && t == tl);
+                todo &= ~peers;
+                if ((int)lane == leader) atomicAdd(&counts[tl], (uint32_t)__builtin_popcountll(peers));
             }
         }
     }
