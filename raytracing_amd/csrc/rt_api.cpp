@@ -387,8 +387,15 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(hipMalloc((void**)&w.bin_offsets, ((size_t)n_rt + 1) * 4));
             w.bin_tiles = n_rt;
         }
+        if (w.bin_recs_tris < n_packed) {
+            if (w.bin_recs) (void)hipFree(w.bin_recs);
+            w.bin_recs = nullptr;
+            w.bin_recs_tris = 0;
+            HIP_TRY(hipMalloc((void**)&w.bin_recs, (size_t)n_packed * 96));
+            w.bin_recs_tris = n_packed;
+        }
         HIP_TRY(rtk::raster_bin(s->view, dp, n_packed, w.cam_table, n_rt, w.bin_counts, w.bin_offsets, w.bin_list,
-                                (uint32_t)w.bin_capacity, false, stream));
+                                (uint32_t)w.bin_capacity, w.bin_recs, false, stream));
         const uint32_t key[5] = {p->width, p->height, p->grid, p->shard_index, p->shard_count};
         if (!w.bin_list || std::memcmp(key, w.bin_key, sizeof(key)) != 0) {
             // First frame of this shape: the lists' total length, read back once.
@@ -405,7 +412,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             std::memcpy(w.bin_key, key, sizeof(key));
         }
         HIP_TRY(rtk::raster_bin(s->view, dp, n_packed, w.cam_table, n_rt, w.bin_counts, w.bin_offsets, w.bin_list,
-                                (uint32_t)w.bin_capacity, true, stream));
+                                (uint32_t)w.bin_capacity, w.bin_recs, true, stream));
     } else if (raster) {
         const size_t words = (size_t)p->width * p->height * spp;
         if (w.zbuf_words < words) {
@@ -427,8 +434,8 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
         const LightProj lp = light_projection(s, p, n_slots);
         if (raster_by_tile) {
-            HIP_TRY(rtk::raster_tiles(s->view, dp, lp, d_list, w.cam_table, w.bin_offsets, w.bin_list, w.samp, w.state,
-                                      w.keys[0], d_stats, stream));
+            HIP_TRY(rtk::raster_tiles(s->view, dp, lp, d_list, w.cam_table, w.bin_offsets, w.bin_list, w.bin_recs, w.samp,
+                                      w.state, w.keys[0], d_stats, stream));
         } else if (raster) {
             HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], d_stats, stream));
         } else {

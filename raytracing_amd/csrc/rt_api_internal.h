@@ -81,12 +81,14 @@ struct FrameWork {
     size_t bin_tiles = 0;
     uint32_t* bin_list = nullptr;
     size_t bin_capacity = 0;
+    float4* bin_recs = nullptr;      // per triangle: what the counting pass prepared (96 B)
+    size_t bin_recs_tris = 0;
     uint32_t bin_key[5] = {0, 0, 0, 0, 0};   // width, height, grid, shard_index, shard_count
     void* temp = nullptr;
     size_t temp_bytes = 0;
     void release() {
         for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp,
-                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list})
+                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list, (void*)bin_recs})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }

@@ -136,6 +136,49 @@ __device__ __forceinline__ rt_tri_eval tri_intersect(rt_f3 e1, rt_f3 e2, rt_f3 v
     return rt_tri_eval{t, u, v, failed};
 }
 
+// The same test in two steps, for callers that can stop after the first: tri_begin computes what
+// the u coordinate needs, tri_finish the rest; together they perform exactly tri_intersect's
+// operations in tri_intersect's order.
+struct rt_tri_head {
+    rt_f3 q, s;
+    float a, un;   // a = e1 . (d x e2), un = s . (d x e2)  (u = (1 / a) * un)
+};
+__device__ __forceinline__ rt_tri_head tri_begin(rt_f3 e1, rt_f3 e2, rt_f3 v0, rt_f3 o, rt_f3 d) {
+    rt_tri_head h;
+    h.q = s_cross(d, e2);
+    h.a = s_dot(e1, h.q);
+    h.s = o - v0;
+    h.un = s_dot(h.s, h.q);
+    return h;
+}
+// True only when tri_finish would report `failed` (or a NaN t) for this lane, decided from the
+// head alone: |a| below the reference's epsilon (its own first term); un and a of opposite sign,
+// which makes u = fl(fl(1 / a) * un) negative unless the product underflows (excluded by the
+// magnitude guard); |un| above |a| by more than the two roundings of u can undo, which makes
+// u > 1 and, v being >= 0 or the test failed anyway, u + v > 1. NaN operands reject nothing.
+// Valid when no intermediate can overflow (coordinates far below 1e18): then v and t are not NaN
+// unless a or un is.
+__device__ __forceinline__ bool tri_head_fails(const rt_tri_head& h) {
+    const float aa = __builtin_fabsf(h.a), au = __builtin_fabsf(h.un);
+    const bool tiny = (h.a > -RT_F32_EPS) && (h.a < RT_F32_EPS);
+    const bool neg = (h.un * h.a < 0.0f) && (au > 1e-30f * aa);
+    const bool big = au > 1.000001f * aa;
+    return tiny || neg || big;
+}
+__device__ __forceinline__ rt_tri_eval tri_finish(const rt_tri_head& h, rt_f3 e1, rt_f3 e2, rt_f3 d) {
+    float f = 1.0f / h.a;
+    float u = f * h.un;
+    rt_f3 r = s_cross(h.s, e1);
+    float v = f * s_dot(d, r);
+    float t = f * s_dot(e2, r);
+    bool failed = (h.a > -RT_F32_EPS) && (h.a < RT_F32_EPS);
+    failed = failed || (u < 0.0f);
+    failed = failed || (v < 0.0f);
+    failed = failed || ((u + v) > 1.0f);
+    failed = failed || (t < 0.0f);
+    return rt_tri_eval{t, u, v, failed};
+}
+
 // _mm256_max_ps / _mm256_min_ps: the SECOND operand is returned when either is NaN.
 __device__ __forceinline__ float x86_max(float a, float b) { return (a > b) ? a : b; }
 __device__ __forceinline__ float x86_min(float a, float b) { return (a < b) ? a : b; }

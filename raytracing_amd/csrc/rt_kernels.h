@@ -46,10 +46,10 @@ hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const L
 // entries). raster_tiles then finds the nearest hits of the launch's tiles and writes their records.
 hipError_t raster_bin(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
                       uint32_t n_raster_tiles, uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_list, uint32_t capacity,
-                      bool fill, hipStream_t s);
+                      float4* d_recs, bool fill, hipStream_t s);
 hipError_t raster_tiles(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                        const float* d_table, const uint32_t* d_offsets, const uint32_t* d_list, float4* d_samp,
-                        uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s);
+                        const float* d_table, const uint32_t* d_offsets, const uint32_t* d_list, const float4* d_recs,
+                        float4* d_samp, uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s);
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
                      DevStats* d_stats, hipStream_t s);

@@ -277,6 +277,10 @@ __device__ __forceinline__ uint32_t sload1u(const void* p) { return *(const RT_C
 #pragma clang diagnostic pop
 
 #define RT_INF_BITS 0x7f800000
+// Shadow rays: stop a triangle test after its first coordinate when that fails for every lane.
+#ifndef RT_ANY_EARLY_OUT
+#define RT_ANY_EARLY_OUT 1
+#endif
 #define RT_BALLOT(pred) __ballot(pred)
 
 
@@ -309,7 +313,7 @@ struct WaveStack {
 template <bool ANY, bool STATS>
 __device__ __forceinline__ void packet_tri(const f32x8_t ra, const f32x4_t rb, uint32_t obj_index, bool& pred, rt_f3 o,
                                            rt_f3 d, float& closest, uint32_t& local_best, HitD& hit, bool& active,
-                                           bool& occluded, LaneStats& st) {
+                                           bool& occluded, LaneStats& st, bool sv_bounded) {
     {
         const rt_f3 v0 = f3(ra[0], ra[1], ra[2]);
         const rt_f3 e1 = f3(ra[3], ra[4], ra[5]);
@@ -317,14 +321,19 @@ __device__ __forceinline__ void packet_tri(const f32x8_t ra, const f32x4_t rb, u
         const uint32_t id = __float_as_uint(rb[1]);
         if (STATS && pred) st.tri += 1;
         if (STATS && (threadIdx.x & 63u) == 0u) st.bytes += 48;
-        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
         if (ANY) {
+            // Shadow rays: most triangles a wave fetches hit none of its rays, and most of those fail
+            // on the first coordinate for every lane: the wave then skips the division and the rest.
+            const rt_tri_head hd = tri_begin(e1, e2, v0, o, d);
+            if (RT_ANY_EARLY_OUT && sv_bounded && __ballot(pred && !tri_head_fails(hd)) == 0ull) return;
+            const rt_tri_eval ev = tri_finish(hd, e1, e2, d);
             if (pred && !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t)) {
                 occluded = true;
                 active = false;
                 pred = false;
             }
         } else {
+            const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
             const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
             if (pred && !ev.failed && ev.t > 0.0f && better) {
                 closest = ev.t;
@@ -348,6 +357,8 @@ __device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, u
                                             f32x8_t ra0 = f32x8_t{}, f32x4_t rb0 = f32x4_t{}) {
     const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
     const uint32_t n = (ref & 7u) + 1u;
+    // Products of coordinate differences stay far from overflow (see tri_head_fails).
+    const bool bounded = sv.scene_extent < 1.0e12f;
     for (uint32_t i = 0; i < n; ++i) {
         f32x8_t ra = ra0;
         f32x4_t rb = rb0;
@@ -356,7 +367,7 @@ __device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, u
             ra = sload8(rp);
             rb = sload4(rp + 32);
         }
-        packet_tri<ANY, STATS>(ra, rb, obj_index, pred, o, d, closest, local_best, hit, active, occluded, st);
+        packet_tri<ANY, STATS>(ra, rb, obj_index, pred, o, d, closest, local_best, hit, active, occluded, st, bounded);
     }
 }
 
@@ -808,6 +819,38 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
     return h;
 }
 
+// Any-hit search of one object's tree for the lanes `in_obj` (one ray per lane): first the whole
+// wave as one beam; failing that, one cell's lanes at a time, each as a beam if it forms one and by
+// the mask walk otherwise. Returns the lane's "occluded".
+template <bool STATS>
+__device__ __forceinline__ bool any_object_tree(const SceneView& sv, uint32_t wide_root, uint32_t root, uint32_t oi, rt_f3 o,
+                                                rt_f3 d, rt_f3 inv, bool in_obj, uint32_t cell, uint2* beam_lds,
+                                                LaneStats& st) {
+    float closest = RT_INF;
+    HitD dummy;
+    bool occ = false;
+    bool todo = in_obj, whole = true;
+    for (;;) {
+        const unsigned long long tm = __ballot(todo);
+        if (tm == 0ull) break;
+        bool grp = todo;
+        if (!whole) {
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, __builtin_ctzll(tm));
+            grp = todo && cell == c0;
+        }
+        // A group equal to the whole wave has already failed as a beam.
+        const bool same = !whole && __ballot(grp) == __ballot(in_obj);
+        bool done = !same && beam_try<true, STATS>(sv, wide_root, oi, o, d, grp, closest, dummy, occ, beam_lds, st);
+        if (!done && !whole) {
+            packet_search<true, STATS>(sv, root, oi, o, d, inv, grp, closest, dummy, occ, st);
+            done = true;
+        }
+        if (done) todo = todo && !grp;
+        whole = false;
+    }
+    return occ;
+}
+
 // `cell` groups the lanes: when the whole wave does not form a usable beam, the lanes of one
 // cell at a time are tried as a beam of their own (rays sorted by a spatial key share a cell with
 // their neighbours; a wave that straddles two distant cells splits into two thin beams).
@@ -828,31 +871,7 @@ __device__ __forceinline__ bool any_all_packet(const SceneView& sv, rt_f3 o, rt_
         const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
         if (RT_BALLOT(in_obj) == 0ull) continue;
         if (root != EMPTY) {
-            float closest = RT_INF;
-            HitD dummy;
-            bool occ = false;
-            // First the whole wave as one beam; failing that, one cell's lanes at a time, each as
-            // a beam if it forms one and by the mask walk otherwise.
-            bool todo = in_obj, whole = true;
-            for (;;) {
-                const unsigned long long tm = __ballot(todo);
-                if (tm == 0ull) break;
-                bool grp = todo;
-                if (!whole) {
-                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, __builtin_ctzll(tm));
-                    grp = todo && cell == c0;
-                }
-                // A group equal to the whole wave has already failed as a beam.
-                const bool same = !whole && __ballot(grp) == __ballot(in_obj);
-                bool done = !same && beam_try<true, STATS>(sv, wide_root, oi, o, d, grp, closest, dummy, occ, beam_lds, st);
-                if (!done && !whole) {
-                    packet_search<true, STATS>(sv, root, oi, o, d, inv, grp, closest, dummy, occ, st);
-                    done = true;
-                }
-                if (done) todo = todo && !grp;
-                whole = false;
-            }
-            if (occ) {
+            if (any_object_tree<STATS>(sv, wide_root, root, oi, o, d, inv, in_obj, cell, beam_lds, st)) {
                 occluded = true;
                 active = false;
             }
@@ -2196,6 +2215,38 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
 #define RT_RTILE_TRIS 64   // triangles of a tile's list a wave sets up at a time
 #endif
 
+// A triangle made ready once per frame by the counting pass of the binning and read back by the
+// list-writing pass and by the tile kernel: 96 bytes, six float4.
+//   0: gu.xyz gv.x   1: gv.yz gw.xy   2: gw.z, u0 | u1 << 16, w0 | w1 << 16, object word
+//   3: e1.xyz e2.x   4: e2.yz v0.xy   5: v0.z - - -
+// The box is stored clipped to the sample grid (fewer than 65,536 columns and rows); an empty box as
+// u0 = 1, u1 = 0.
+#define RT_RREC 6
+#define RT_BIN_HASH_BITS 9
+#define RT_BIN_HASH (1u << RT_BIN_HASH_BITS)   // slots of a workgroup's table of tiles
+__device__ __forceinline__ void raster_rec_store(float4* __restrict__ r, const RasterTri& rt) {
+    const bool any = rt.u0 <= rt.u1 && rt.w0 <= rt.w1;
+    const uint32_t bu = any ? ((uint32_t)rt.u0 | ((uint32_t)rt.u1 << 16)) : 1u;
+    const uint32_t bw = any ? ((uint32_t)rt.w0 | ((uint32_t)rt.w1 << 16)) : 1u;
+    r[0] = make_float4(rt.rs.gu.x, rt.rs.gu.y, rt.rs.gu.z, rt.rs.gv.x);
+    r[1] = make_float4(rt.rs.gv.y, rt.rs.gv.z, rt.rs.gw.x, rt.rs.gw.y);
+    r[2] = make_float4(rt.rs.gw.z, __uint_as_float(bu), __uint_as_float(bw), __uint_as_float(rt.objword));
+    r[3] = make_float4(rt.e1.x, rt.e1.y, rt.e1.z, rt.e2.x);
+    r[4] = make_float4(rt.e2.y, rt.e2.z, rt.v0.x, rt.v0.y);
+    r[5] = make_float4(rt.v0.z, 0.0f, 0.0f, 0.0f);
+}
+// The half-planes and the box of a stored record (what the binning needs).
+__device__ __forceinline__ void raster_rec_head(const float4* __restrict__ r, RasterSetup& rs, int& u0, int& u1, int& w0,
+                                                int& w1, uint32_t& objword) {
+    const float4 a = r[0], b = r[1], c = r[2];
+    rs.gu = f3(a.x, a.y, a.z), rs.gv = f3(a.w, b.x, b.y), rs.gw = f3(b.z, b.w, c.x);
+    rs.grow = 0.0f;
+    rs.visible = true;
+    const uint32_t bu = __float_as_uint(c.y), bw = __float_as_uint(c.z);
+    u0 = (int)(bu & 0xFFFFu), u1 = (int)(bu >> 16), w0 = (int)(bw & 0xFFFFu), w1 = (int)(bw >> 16);
+    objword = __float_as_uint(c.w);
+}
+
 // Raster tiles of the frame: ceil(gw / 32) x ceil(gh / 32), numbered row by row.
 __device__ __forceinline__ bool raster_tile_owned(const DevRenderParams& p, uint32_t gs, uint32_t rtx, uint32_t rty) {
     if (p.shard_count <= 1) return true;
@@ -2203,31 +2254,49 @@ __device__ __forceinline__ bool raster_tile_owned(const DevRenderParams& p, uint
     return (ptx + pty) % p.shard_count == p.shard_index;
 }
 
-// True when no sample of the rectangle [x0, x1] x [y0, y1] can pass the three half-planes (see the
-// block test in k_raster: the functions are monotone in the table's columns and rows).
-__device__ __forceinline__ bool raster_rect_outside(const RasterSetup& rs, const float* __restrict__ tab, int gw, int x0,
-                                                    int x1, int y0, int y1) {
-    const float dx_lo = tab[x0], dx_hi = tab[x1], dy_hi = tab[gw + y0], dy_lo = tab[gw + y1];
+// True when no sample of the rectangle [x0, x1] x [y0, y1] can pass the three half-planes: each
+// function is linear in (dx, dy), so its largest value over the rectangle is taken at a corner, and
+// the rectangle is outside as soon as one function is negative there. The corners are taken 1/16
+// sample beyond the rectangle, from the closed form of the table (dx = (column + 0.5) / ax - aspect,
+// dy = 1 - (row + 0.5) / ay): the tabulated values differ from it by a few units of their last place,
+// under 0.02 sample for the widest frames the projection takes, so the corner values bound the table's.
+struct RasterGrid {
+    float inv_ax, inv_ay, aspect;
+};
+__device__ __forceinline__ bool raster_rect_outside(const RasterSetup& rs, const RasterGrid& gr, int x0, int x1, int y0,
+                                                    int y1) {
+    const float dx_lo = ((float)x0 + 0.4375f) * gr.inv_ax - gr.aspect, dx_hi = ((float)x1 + 0.5625f) * gr.inv_ax - gr.aspect;
+    const float dy_hi = 1.0f - ((float)y0 + 0.4375f) * gr.inv_ay, dy_lo = 1.0f - ((float)y1 + 0.5625f) * gr.inv_ay;
     const float fu = __builtin_fmaf(rs.gu.x < 0.0f ? dx_lo : dx_hi, rs.gu.x, __builtin_fmaf(rs.gu.y < 0.0f ? dy_lo : dy_hi, rs.gu.y, rs.gu.z));
     const float fv = __builtin_fmaf(rs.gv.x < 0.0f ? dx_lo : dx_hi, rs.gv.x, __builtin_fmaf(rs.gv.y < 0.0f ? dy_lo : dy_hi, rs.gv.y, rs.gv.z));
     const float fw = __builtin_fmaf(rs.gw.x < 0.0f ? dx_lo : dx_hi, rs.gw.x, __builtin_fmaf(rs.gw.y < 0.0f ? dy_lo : dy_hi, rs.gw.y, rs.gw.z));
     return (fu < 0.0f) || (fv < 0.0f) || (fw < 0.0f);
 }
 
-// One lane per triangle. FILL == false: counts[t] += 1 for every tile t the triangle goes to.
+// One lane per triangle, workgroups of 256. FILL == false: counts[t] += 1 for every tile t the triangle goes to.
 // FILL == true: list[offsets[t] + counts[t]++] = triangle id (counts zeroed in between; `capacity`
 // entries at most are written).
 template <bool FILL>
 __global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_total, const float* __restrict__ tab,
                              uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                             uint32_t* __restrict__ list, uint32_t capacity) {
+                             uint32_t* __restrict__ list, uint32_t capacity, float4* __restrict__ recs) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = id < n_tris_total;
     const uint32_t g = p.grid, gs = 31u - (uint32_t)__builtin_clz(g);
-    const float aspect = (float)(p.width / p.height);
-    const int gw = (int)(p.width * g), gh = (int)(p.height * g);
-    uint32_t unused = 0;
-    const RasterTri rt = raster_prepare(sv, p, valid ? id : 0u, gw, gh, aspect, unused);
+    const int gw = (int)(p.width * g);
+    RasterGrid gr;
+    gr.aspect = (float)(p.width / p.height);
+    gr.inv_ax = 1.0f / ((float)gw * 0.5f / gr.aspect);
+    gr.inv_ay = 1.0f / ((float)(p.height * g) * 0.5f);
+    RasterTri rt;
+    if (FILL) {
+        // the counting pass has left the triangle's half-planes and box
+        raster_rec_head(recs + (size_t)RT_RREC * (valid ? id : 0u), rt.rs, rt.u0, rt.u1, rt.w0, rt.w1, rt.objword);
+    } else {
+        uint32_t unused = 0;
+        rt = raster_prepare(sv, p, valid ? id : 0u, gw, (int)(p.height * g), gr.aspect, unused);
+        if (valid) raster_rec_store(recs + (size_t)RT_RREC * id, rt);
+    }
     const uint32_t ntx = ((uint32_t)gw + RT_RTILE - 1u) / RT_RTILE;
     const bool any = valid && rt.u0 <= rt.u1 && rt.w0 <= rt.w1;
     const uint32_t tx0 = any ? (uint32_t)rt.u0 / RT_RTILE : 1u, tx1 = any ? (uint32_t)rt.u1 / RT_RTILE : 0u;
@@ -2254,50 +2323,73 @@ __global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_to
             if (!raster_tile_owned(p, gs, txk, tyk)) continue;
             const int x0 = max(u0, (int)(txk * RT_RTILE)), x1 = min(u1, (int)(txk * RT_RTILE + RT_RTILE - 1u));
             const int y0 = max(w0, (int)(tyk * RT_RTILE)), y1 = min(w1, (int)(tyk * RT_RTILE + RT_RTILE - 1u));
-            if (raster_rect_outside(rs, tab, gw, x0, x1, y0, y1)) continue;
+            if (raster_rect_outside(rs, gr, x0, x1, y0, y1)) continue;
             const uint32_t t = tyk * ntx + txk;
             const uint32_t pos = atomicAdd(&counts[t], 1u);
             if (FILL && offsets[t] + pos < capacity) list[offsets[t] + pos] = bid;
         }
     }
-    // The other lanes walk their own triangles' tiles; the wave keeps turning until all are through.
-    // Neighbouring triangles go to the same few tiles, so the lanes that name one tile in a turn add
-    // to its counter together: one atomic per distinct tile and turn instead of one per lane.
-    uint32_t tx = tx0, ty = ty0;
-    bool walking = any && !big;
-    while (__ballot(walking) != 0ull) {
-        bool want = false;
-        uint32_t t = 0xFFFFFFFFu;
-        if (walking) {
+    // The other lanes walk their own triangles' tiles. The 256 consecutive triangles of a workgroup go
+    // to a few dozen tiles between them, so the group first gathers its entries per tile in a small hash
+    // table in LDS and then touches each tile's global counter once: a tenth of the atomics, which
+    // were what the pass spent most of its time on. An entry that finds no room in the table (a group
+    // whose triangles are scattered over the frame) goes to the global counter directly.
+    __shared__ uint32_t h_key[RT_BIN_HASH], h_cnt[RT_BIN_HASH], h_base[RT_BIN_HASH];
+    for (uint32_t i = threadIdx.x; i < RT_BIN_HASH; i += blockDim.x) h_key[i] = 0xFFFFFFFFu, h_cnt[i] = 0u;
+    __syncthreads();
+    // Walks the lane's tiles; emit(tile) is called for every tile the triangle goes to.
+    auto walk = [&](auto&& emit) {
+        uint32_t tx = tx0, ty = ty0;
+        for (bool walking = any && !big; walking;) {
             if (raster_tile_owned(p, gs, tx, ty)) {
                 const int x0 = max(rt.u0, (int)(tx * RT_RTILE)), x1 = min(rt.u1, (int)(tx * RT_RTILE + RT_RTILE - 1u));
                 const int y0 = max(rt.w0, (int)(ty * RT_RTILE)), y1 = min(rt.w1, (int)(ty * RT_RTILE + RT_RTILE - 1u));
-                want = !raster_rect_outside(rt.rs, tab, gw, x0, x1, y0, y1);
-                t = ty * ntx + tx;
+                if (!raster_rect_outside(rt.rs, gr, x0, x1, y0, y1)) emit(ty * ntx + tx);
             }
             if (++tx > tx1) {
                 tx = tx0;
                 walking = ++ty <= ty1;
             }
         }
-        if (FILL) {
-            // Every lane takes its own place in its tile's list: 64 returning atomics in flight
-            // together are faster than one per distinct tile waited for in turn.
-            if (want) {
-                const uint32_t pos = offsets[t] + atomicAdd(&counts[t], 1u);
-                if (pos < capacity) list[pos] = id;
-            }
-        } else {
-            unsigned long long todo = __ballot(want);
-            while (todo != 0ull) {
-                const int leader = __builtin_ctzll(todo);
-                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
-                const unsigned long long peers = __ballot(want && t == tl);
-                todo &= ~peers;
-                if ((int)lane == leader) atomicAdd(&counts[tl], (uint32_t)__builtin_popcountll(peers));
-            }
+    };
+    // The table slot of tile t, claimed if `insert`; RT_BIN_HASH when there is none.
+    auto slot_of = [&](uint32_t t, bool insert) -> uint32_t {
+        uint32_t h = (t * 0x9E3779B1u) >> (32 - RT_BIN_HASH_BITS);
+        for (int probe = 0; probe < 16; ++probe) {
+            uint32_t k = h_key[h];
+            if (k == 0xFFFFFFFFu && insert) k = atomicCAS(&h_key[h], 0xFFFFFFFFu, t), k = k == 0xFFFFFFFFu ? t : k;
+            if (k == t) return h;
+            if (k == 0xFFFFFFFFu) return RT_BIN_HASH;   // not inserting, and the chain ends here
+            h = (h + 1u) & (RT_BIN_HASH - 1u);
         }
+        return RT_BIN_HASH;
+    };
+    // First walk: entries per tile of this group; entries without a slot are placed at once.
+    walk([&](uint32_t t) {
+        const uint32_t sl = slot_of(t, true);
+        if (sl < RT_BIN_HASH) {
+            atomicAdd(&h_cnt[sl], 1u);
+        } else {
+            const uint32_t pos = atomicAdd(&counts[t], 1u);
+            if (FILL && offsets[t] + pos < capacity) list[offsets[t] + pos] = id;
+        }
+    });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < RT_BIN_HASH; i += blockDim.x) {
+        const uint32_t t = h_key[i];
+        if (t == 0xFFFFFFFFu) continue;
+        const uint32_t before = atomicAdd(&counts[t], h_cnt[i]);
+        if (FILL) h_base[i] = offsets[t] + before, h_cnt[i] = 0u;
     }
+    if (!FILL) return;
+    __syncthreads();
+    // Second walk: every entry takes its place in the stretch of the list the group has reserved.
+    walk([&](uint32_t t) {
+        const uint32_t sl = slot_of(t, false);
+        if (sl == RT_BIN_HASH) return;   // placed by the first walk
+        const uint32_t pos = h_base[sl] + atomicAdd(&h_cnt[sl], 1u);
+        if (pos < capacity) list[pos] = id;
+    });
 }
 
 // offsets[i] = counts[0] + ... + counts[i - 1] for i = 0 .. n (offsets[n] = the total); counts are
@@ -2403,6 +2495,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                                                        const float* __restrict__ tab,
                                                        const uint32_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ list,
+                                                       const float4* __restrict__ recs,
                                                        float4* __restrict__ samp, uint32_t* __restrict__ state,
                                                        uint32_t* __restrict__ keys, DevStats* __restrict__ stats) {
     __shared__ RasterTileLds lds;
@@ -2474,18 +2567,21 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         rs.gu = rs.gv = rs.gw = f3(0.0f, 0.0f, 0.0f);
         if (lane < RT_RTILE_TRIS && base + lane < n_list) {
             const uint32_t id = list[first + base + lane];
-            if (STATS) st.bytes += 4;
-            const RasterTri rt = raster_prepare(sv, p, id, gw, gh, aspect, st.bytes);
-            rs = rt.rs;
-            c0 = max(rt.u0 - su0, 0), c1 = min(rt.u1 - su0, (int)RT_RTILE - 1);
-            r0 = max(rt.w0 - sw0, 0), r1 = min(rt.w1 - sw0, (int)RT_RTILE - 1);
+            const float4* r = recs + (size_t)RT_RREC * id;
+            if (STATS) st.bytes += 4 + 16 * RT_RREC;
+            int u0, u1, w0, w1;
+            uint32_t objword;
+            raster_rec_head(r, rs, u0, u1, w0, w1, objword);
+            const float4 t3 = r[3], t4 = r[4], t5 = r[5];
+            c0 = max(u0 - su0, 0), c1 = min(u1 - su0, (int)RT_RTILE - 1);
+            r0 = max(w0 - sw0, 0), r1 = min(w1 - sw0, (int)RT_RTILE - 1);
             if (c0 > c1) r1 = r0 - 1;
             float* td = lds.tri[wv][lane];
-            td[0] = rt.e1.x, td[1] = rt.e1.y, td[2] = rt.e1.z;
-            td[3] = rt.e2.x, td[4] = rt.e2.y, td[5] = rt.e2.z;
-            td[6] = rt.v0.x, td[7] = rt.v0.y, td[8] = rt.v0.z;
+            td[0] = t3.x, td[1] = t3.y, td[2] = t3.z;
+            td[3] = t3.w, td[4] = t4.x, td[5] = t4.y;
+            td[6] = t4.z, td[7] = t4.w, td[8] = t5.x;
             td[9] = __uint_as_float(id);
-            td[10] = __uint_as_float(rt.objword);
+            td[10] = __uint_as_float(objword);
         }
         // slope and offset of the boundary column as a function of the row's r = fma(dy, gy, gz)
         const float off = (aspect * ax - 0.5f) - (float)su0;
@@ -3103,7 +3199,7 @@ hipError_t raster_depth(const SceneView& sv, const DevRenderParams& p, uint32_t 
 
 hipError_t raster_bin(const SceneView& sv, const DevRenderParams& p, uint32_t n_tris_total, float* d_table,
                       uint32_t n_raster_tiles, uint32_t* d_counts, uint32_t* d_offsets, uint32_t* d_list, uint32_t capacity,
-                      bool fill, hipStream_t s) {
+                      float4* d_recs, bool fill, hipStream_t s) {
     if (n_tris_total == 0) return hipSuccess;
     const dim3 grid((n_tris_total + 255u) / 256u);
     if (!fill) {
@@ -3111,25 +3207,25 @@ hipError_t raster_bin(const SceneView& sv, const DevRenderParams& p, uint32_t n_
         hipLaunchKernelGGL(k_camera_table, dim3((lines + 255) / 256), dim3(256), 0, s, sv, p, d_table);
         hipError_t e = hipMemsetAsync(d_counts, 0, (size_t)n_raster_tiles * 4, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_raster_bin<false>, grid, dim3(256), 0, s, sv, p, n_tris_total, d_table, d_counts, d_offsets, d_list, capacity);
+        hipLaunchKernelGGL(k_raster_bin<false>, grid, dim3(256), 0, s, sv, p, n_tris_total, d_table, d_counts, d_offsets, d_list, capacity, d_recs);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, d_counts, n_raster_tiles, d_offsets);
     } else {
-        hipLaunchKernelGGL(k_raster_bin<true>, grid, dim3(256), 0, s, sv, p, n_tris_total, d_table, d_counts, d_offsets, d_list, capacity);
+        hipLaunchKernelGGL(k_raster_bin<true>, grid, dim3(256), 0, s, sv, p, n_tris_total, d_table, d_counts, d_offsets, d_list, capacity, d_recs);
     }
     return hipGetLastError();
 }
 
 hipError_t raster_tiles(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, const uint32_t* d_tile_list,
-                        const float* d_table, const uint32_t* d_offsets, const uint32_t* d_list, float4* d_samp,
-                        uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s) {
+                        const float* d_table, const uint32_t* d_offsets, const uint32_t* d_list, const float4* d_recs,
+                        float4* d_samp, uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s) {
     const uint32_t waves = p.n_tiles * p.spp;   // g x g raster tiles of 32 x 32 samples per tile of 32 x 32 pixels
     if (waves == 0) return hipSuccess;
     if (d_stats)
         hipLaunchKernelGGL(k_raster_tile<true>, dim3(waves), dim3(64 * RT_RTILE_GROUP), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
-                           d_samp, d_state, d_keys, d_stats);
+                           d_recs, d_samp, d_state, d_keys, d_stats);
     else
         hipLaunchKernelGGL(k_raster_tile<false>, dim3(waves), dim3(64 * RT_RTILE_GROUP), 0, s, sv, p, lp, d_tile_list, d_table, d_offsets, d_list,
-                           d_samp, d_state, d_keys, d_stats);
+                           d_recs, d_samp, d_state, d_keys, d_stats);
     return hipGetLastError();
 }
 
