@@ -2525,6 +2525,29 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     const uint32_t ntx = ((uint32_t)gw + RT_RTILE - 1u) / RT_RTILE;
     const bool on_frame = su0 < gw && sw0 < gh;
 
+    // The tile's list, and the first stretch of it: the loads are issued before the tile's words in LDS
+    // are set up, and every later stretch is fetched while the one before it is worked on.
+    const uint32_t rt_index = rty * ntx + rtx;
+    const uint32_t first = on_frame ? offsets[rt_index] : 0u, n_list = on_frame ? offsets[rt_index + 1] - first : 0u;
+    struct Stretch {
+        bool valid;
+        uint32_t id;
+        float4 r0, r1, r2, r3, r4, r5;
+    };
+    auto fetch = [&](uint32_t base) {
+        Stretch c;
+        c.valid = lane < RT_RTILE_TRIS && base + lane < n_list;
+        c.id = 0;
+        c.r0 = c.r1 = c.r2 = c.r3 = c.r4 = c.r5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c.valid) {
+            c.id = list[first + base + lane];
+            const float4* r = recs + (size_t)RT_RREC * c.id;
+            c.r0 = r[0], c.r1 = r[1], c.r2 = r[2], c.r3 = r[3], c.r4 = r[4], c.r5 = r[5];
+        }
+        return c;
+    };
+    Stretch cur = fetch(wv * RT_RTILE_TRIS);
+
     for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE; i += 64u * RT_RTILE_GROUP) lds.z[i] = RT_ZKEY_NONE;
     if (threadIdx.x < RT_RTILE) lds.dx[threadIdx.x] = tab[min(su0 + (int)threadIdx.x, gw - 1)];
     else if (threadIdx.x < 2u * RT_RTILE) lds.dy[threadIdx.x - RT_RTILE] = tab[gw + min(sw0 + (int)(threadIdx.x - RT_RTILE), gh - 1)];
@@ -2555,8 +2578,6 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         atomicMin(&lds.z[zi], ((unsigned long long)__float_as_uint(ev.t) << 32) | id);
     };
 
-    const uint32_t rt_index = rty * ntx + rtx;
-    const uint32_t first = on_frame ? offsets[rt_index] : 0u, n_list = on_frame ? offsets[rt_index + 1] - first : 0u;
     // Column of image-plane x: dx = (column + 0.5) / ax - aspect up to rounding, so a half-plane's
     // boundary along a row, fma(dx, gx, r) = 0, lies near column (aspect - r / gx) * ax - 0.5.
     const float ax = (float)gw * 0.5f / aspect;
@@ -2565,24 +2586,23 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         int c0 = 0, c1 = -1, r0 = 0, r1 = -1;
         RasterSetup rs;
         rs.gu = rs.gv = rs.gw = f3(0.0f, 0.0f, 0.0f);
-        if (lane < RT_RTILE_TRIS && base + lane < n_list) {
-            const uint32_t id = list[first + base + lane];
-            const float4* r = recs + (size_t)RT_RREC * id;
+        if (cur.valid) {
             if (STATS) st.bytes += 4 + 16 * RT_RREC;
-            int u0, u1, w0, w1;
-            uint32_t objword;
-            raster_rec_head(r, rs, u0, u1, w0, w1, objword);
-            const float4 t3 = r[3], t4 = r[4], t5 = r[5];
+            const float4 a = cur.r0, b = cur.r1, c = cur.r2;
+            rs.gu = f3(a.x, a.y, a.z), rs.gv = f3(a.w, b.x, b.y), rs.gw = f3(b.z, b.w, c.x);
+            const uint32_t bu = __float_as_uint(c.y), bw = __float_as_uint(c.z);
+            const int u0 = (int)(bu & 0xFFFFu), u1 = (int)(bu >> 16), w0 = (int)(bw & 0xFFFFu), w1 = (int)(bw >> 16);
             c0 = max(u0 - su0, 0), c1 = min(u1 - su0, (int)RT_RTILE - 1);
             r0 = max(w0 - sw0, 0), r1 = min(w1 - sw0, (int)RT_RTILE - 1);
             if (c0 > c1) r1 = r0 - 1;
             float* td = lds.tri[wv][lane];
-            td[0] = t3.x, td[1] = t3.y, td[2] = t3.z;
-            td[3] = t3.w, td[4] = t4.x, td[5] = t4.y;
-            td[6] = t4.z, td[7] = t4.w, td[8] = t5.x;
-            td[9] = __uint_as_float(id);
-            td[10] = __uint_as_float(objword);
+            td[0] = cur.r3.x, td[1] = cur.r3.y, td[2] = cur.r3.z;
+            td[3] = cur.r3.w, td[4] = cur.r4.x, td[5] = cur.r4.y;
+            td[6] = cur.r4.z, td[7] = cur.r4.w, td[8] = cur.r5.x;
+            td[9] = __uint_as_float(cur.id);
+            td[10] = c.w;
         }
+        if (base + RT_RTILE_TRIS * RT_RTILE_GROUP < n_list) cur = fetch(base + RT_RTILE_TRIS * RT_RTILE_GROUP);
         // slope and offset of the boundary column as a function of the row's r = fma(dy, gy, gz)
         const float off = (aspect * ax - 0.5f) - (float)su0;
         const float ku = -ax * __builtin_amdgcn_rcpf(rs.gu.x), kv = -ax * __builtin_amdgcn_rcpf(rs.gv.x),
