@@ -844,6 +844,8 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     HIP_TRY(pool.alloc((void**)&d_recs, n_recs_total * 48 + 192));  // padded: a leaf is read as 192 B
     HIP_TRY(pool.alloc((void**)&d_nodes, n_nodes_total * sizeof(rtbvh::Node4)));
     HIP_TRY(pool.alloc((void**)&d_wide, n_wide_total * sizeof(rtbvh::Child)));
+    float4* d_qnodes = nullptr;
+    HIP_TRY(pool.alloc((void**)&d_qnodes, std::max<size_t>(n_nodes_total, 1) * 64));
     HIP_TRY(pool.alloc((void**)&d_objs, s->objects.size() * sizeof(DevObject)));
     HIP_TRY(hipMemcpy(d_verts, verts_all.data(), verts_all.size() * 4, hipMemcpyHostToDevice));
     if (!tris_all.empty()) HIP_TRY(hipMemcpy(d_tris, tris_all.data(), tris_all.size() * 4, hipMemcpyHostToDevice));
@@ -915,6 +917,7 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     HIP_TRY(rtk::pack_tris(d_verts, d_tris, (uint32_t)total_tris, d_tri9, 0));
     HIP_TRY(rtk::leaf_bounds(d_verts, d_tris, d_leaf_first, (uint32_t)leaf_first.size(), d_leaf_bounds, 0));
     HIP_TRY(rtk::gather_records(d_tri9, d_order, (uint32_t)n_recs_total, d_recs, 0));
+    HIP_TRY(rtk::quantize_nodes(d_nodes, (uint32_t)n_nodes_total, d_qnodes, 0));
     HIP_TRY(hipDeviceSynchronize());
 
     s->view.objs = d_objs;
@@ -931,6 +934,7 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
         if (const char* e = std::getenv("RAYS_HIP_BEAM_DIV")) s->view.beam_limit = ext / (float)std::atof(e);
     }
     s->view.nodes = d_nodes;
+    s->view.qnodes = d_qnodes;
     s->view.wide = d_wide;
     s->view.recs = d_recs;
     s->view.tri9 = d_tri9;

@@ -41,6 +41,7 @@ struct SceneView {
     const DevObject* objs;
     uint32_t n_objs;
     const rtbvh::Node4* nodes;  // all objects' 4-wide trees, 128 B per node
+    const float4* qnodes;       // the same nodes in 64 B each: child boxes as bytes on the node's own grid (node_step_q)
     const rtbvh::Child* wide;   // all objects' wide trees, 32 B per child
     const float4* recs;         // triangle records in tree-leaf order, 3 x float4 each:
                                 //   (v0.x v0.y v0.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z id - -)

@@ -20,6 +20,8 @@ hipError_t trace_closest_linear(const SceneView& sv, const rt_ray* d_rays, uint6
 hipError_t pack_tris(const float* d_verts, const uint32_t* d_tris, uint32_t n, float* d_tri9, hipStream_t s);
 hipError_t leaf_bounds(const float* d_verts, const uint32_t* d_tris, const uint32_t* d_leaf_first, uint32_t n_leaves,
                        float* d_leaf_bounds, hipStream_t s);
+// The 64-byte form of the 4-wide nodes that the persistent per-lane walk reads (node i -> 4 float4 at 4 i).
+hipError_t quantize_nodes(const rtbvh::Node4* d_nodes, uint32_t n, float4* d_qnodes, hipStream_t s);
 hipError_t gather_records(const float* d_tri9, const uint32_t* d_order, uint32_t n, float4* d_recs, hipStream_t s);
 // mode: 0 camera + shadow rays, 1 + mirror chains, 2 + diffuse scattering (see k_render).
 hipError_t render(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, int mode,

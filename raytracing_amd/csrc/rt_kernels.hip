@@ -42,8 +42,10 @@ template <int NLDS, int STRIDE>
 struct LaneStackT {
     static_assert(NLDS <= RT_STACK_MAX, "stack split");
     uint2* lds;    // &s_stack[threadIdx.x]; entry e lives at lds[e * STRIDE] (STRIDE = workgroup size)
-    uint2 spill[RT_STACK_MAX - NLDS];
+    uint2* spill;  // RT_STACK_MAX - NLDS entries of the kernel's, in private memory (an array inside this
+                   // struct would take sp and lds into private memory with it)
     int sp;
+    static constexpr int REST = RT_STACK_MAX - NLDS;
     __device__ __forceinline__ void push(uint32_t node, float tnear) {
         uint2 e = make_uint2(node, __float_as_uint(tnear));
         if (sp < NLDS) lds[sp * STRIDE] = e;
@@ -108,6 +110,58 @@ __device__ __forceinline__ bool node_step(const SceneView& sv, uint32_t cur, rt_
     RT_BOX(k2, c2, a2, b2)
     RT_BOX(k3, c3, a3, b3)
 #undef RT_BOX
+    RT_CSWAP(k0, k1, c0, c1)
+    RT_CSWAP(k2, k3, c2, c3)
+    RT_CSWAP(k0, k2, c0, c2)
+    RT_CSWAP(k1, k3, c1, c3)
+    RT_CSWAP(k1, k2, c1, c2)
+    if (k3 < RT_INF) stk.push(c3, k3);
+    if (k2 < RT_INF) stk.push(c2, k2);
+    if (k1 < RT_INF) stk.push(c1, k1);
+    *next = c0;
+    return k0 < RT_INF;
+}
+
+// node_step on the compact form of the nodes (64 bytes instead of 128: half the vector-memory
+// instructions per step, which is what bounds the per-lane walk on incoherent rays). A compact node
+// holds its own box corner `origin` and a step `scale` per axis, and every child box as six bytes:
+// lo = origin + q_lo * scale, hi = origin + q_hi * scale, rounded outwards by k_quantize_nodes with a
+// margin that covers the roundings below. Layout, four float4:
+//   0: origin.xyz scale.x   1: scale.yz ref0 ref1   2: ref2 ref3 bytes[0..7]   3: bytes[8..23]
+// bytes[6 k .. 6 k + 5] = lo.x lo.y lo.z hi.x hi.y hi.z of child k. The slab distances come out as
+// t = q * (scale * inv) + (origin * inv - o * inv): one conversion and one fused multiply-add each.
+#define RT_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu))   // one v_cvt_f32_ubyteK
+template <bool STATS, class Stack>
+__device__ __forceinline__ bool node_step_q(const SceneView& sv, uint32_t cur, rt_f3 inv, float nox, float noy, float noz,
+                                            float closest, Stack& stk, LaneStats& st, uint32_t* next) {
+    const float4* np = sv.qnodes + 4 * (size_t)cur;
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    if (STATS) {
+        st.node += 1;
+        st.box += 4;
+        st.bytes += 64;
+    }
+    const float sx = q0.w * inv.x, sy = q1.x * inv.y, sz = q1.y * inv.z;
+    const float ox = __builtin_fmaf(q0.x, inv.x, nox), oy = __builtin_fmaf(q0.y, inv.y, noy), oz = __builtin_fmaf(q0.z, inv.z, noz);
+    uint32_t c0 = __float_as_uint(q1.z), c1 = __float_as_uint(q1.w);
+    uint32_t c2 = __float_as_uint(q2.x), c3 = __float_as_uint(q2.y);
+    const uint32_t w0 = __float_as_uint(q2.z), w1 = __float_as_uint(q2.w), w2 = __float_as_uint(q3.x);
+    const uint32_t w3 = __float_as_uint(q3.y), w4 = __float_as_uint(q3.z), w5 = __float_as_uint(q3.w);
+    float k0, k1, k2, k3;
+#define RT_QBOX(K, C, LX, LY, LZ, HX, HY, HZ)                                                        \
+    {                                                                                                \
+        float ax = __builtin_fmaf(LX, sx, ox), bx = __builtin_fmaf(HX, sx, ox);                      \
+        float ay = __builtin_fmaf(LY, sy, oy), by = __builtin_fmaf(HY, sy, oy);                      \
+        float az = __builtin_fmaf(LZ, sz, oz), bz = __builtin_fmaf(HZ, sz, oz);                      \
+        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));           \
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));        \
+        K = ((C) != EMPTY && tn <= tf) ? tn : RT_INF;                                                \
+    }
+    RT_QBOX(k0, c0, RT_UB(w0, 0), RT_UB(w0, 1), RT_UB(w0, 2), RT_UB(w0, 3), RT_UB(w1, 0), RT_UB(w1, 1))
+    RT_QBOX(k1, c1, RT_UB(w1, 2), RT_UB(w1, 3), RT_UB(w2, 0), RT_UB(w2, 1), RT_UB(w2, 2), RT_UB(w2, 3))
+    RT_QBOX(k2, c2, RT_UB(w3, 0), RT_UB(w3, 1), RT_UB(w3, 2), RT_UB(w3, 3), RT_UB(w4, 0), RT_UB(w4, 1))
+    RT_QBOX(k3, c3, RT_UB(w4, 2), RT_UB(w4, 3), RT_UB(w5, 0), RT_UB(w5, 1), RT_UB(w5, 2), RT_UB(w5, 3))
+#undef RT_QBOX
     RT_CSWAP(k0, k1, c0, c1)
     RT_CSWAP(k2, k3, c2, c3)
     RT_CSWAP(k0, k2, c0, c2)
@@ -923,8 +977,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
     __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
+    uint2 stack_rest[LaneStack::REST];
     LaneStack stk;
     stk.lds = &s_stack[threadIdx.x];
+    stk.spill = stack_rest;
     LaneStats st;
     const rt_ray r = rays[i];
     const HitD h = closest_all<false>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), stk, st);
@@ -985,6 +1041,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #ifndef RT_DYNAMIC_SHIFT
 #define RT_DYNAMIC_SHIFT 2
 #endif
+// The persistent walk reads the compact nodes (node_step_q).
+#ifndef RT_WALK_QNODES
+#define RT_WALK_QNODES 1
+#endif
 #define RT_WALK_MAX_GRID 8192u                              // waves of a persistent launch
 #define RT_WALK_HEADROOM (RT_WALK_MAX_GRID * RT_CHUNK + 64u)  // counter overshoot at the end of a launch
 // Stack of the persistent walk: RT_WALK_LDS entries of 6 bytes in LDS (node reference, and the
@@ -999,7 +1059,9 @@ struct WalkLds {
 struct WalkStack {
     uint32_t* refs;  // &lds.refs[lane]; entry e at refs[e * 64]
     uint16_t* keys;
-    uint2 spill[RT_STACK_MAX - RT_WALK_LDS];
+    uint2* spill;    // RT_STACK_MAX - RT_WALK_LDS entries of the caller's, in private memory. (An array inside
+                     // this struct would drag sp and the two pointers into private memory with it: every
+                     // push and pop then goes through scratch loads and untyped stores.)
     int sp;
     __device__ __forceinline__ void push(uint32_t node, float tnear) {
         if (sp < RT_WALK_LDS) {
@@ -1021,7 +1083,9 @@ template <bool ANY, bool STATS, class Source>
 __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_rays, uint32_t* counter,
                                                 const Source& src, WalkLds& s_stack, LaneStats& st) {
     const uint32_t lane = threadIdx.x & 63u;
+    uint2 stack_rest[RT_STACK_MAX - RT_WALK_LDS];
     WalkStack stk;
+    stk.spill = stack_rest;
     stk.refs = &s_stack.refs[threadIdx.x];
     stk.keys = &s_stack.keys[threadIdx.x];
     stk.sp = 0;
@@ -1162,7 +1226,12 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             bool need_pop = true;
             if (!(cur & LEAF_BIT)) {
                 uint32_t next;
-                if (node_step<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next)) {
+#if RT_WALK_QNODES
+                const bool go = node_step_q<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next);
+#else
+                const bool go = node_step<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next);
+#endif
+                if (go) {
                     cur = next;
                     need_pop = false;
                 }
@@ -1274,8 +1343,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_any(SceneView
     __shared__ uint2 s_stack[RT_STACK_LDS * RT_BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
+    uint2 stack_rest[LaneStack::REST];
     LaneStack stk;
     stk.lds = &s_stack[threadIdx.x];
+    stk.spill = stack_rest;
     LaneStats st;
     const rt_ray r = rays[i];
     occluded[i] = any_all<false>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), stk, st) ? 1 : 0;
@@ -1386,6 +1457,68 @@ __global__ void k_leaf_bounds(const float* __restrict__ verts, const uint32_t* _
     float* o = leaf_bounds + 6 * (size_t)l;
     o[0] = mn.x; o[1] = mn.y; o[2] = mn.z;
     o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+}
+
+// The compact form of the 4-wide nodes that node_step_q reads. One thread per node. The node's box
+// (over its non-empty children) is widened by `pad` on every side, which covers what node_step_q
+// rounds differently from node_step (the boxes themselves already carry the builders' margin for
+// the slab products): the product scale * inv, the sum origin * inv - o * inv and the final fused
+// multiply-add are each within 2^-24 of magnitudes no larger than |coordinate * inv|, and pad is 2^-17
+// of the largest coordinate. Every child corner is then rounded outwards on the grid of 255 steps,
+// and checked in the arithmetic the walk's conversion implies (origin + q * scale, one fma).
+__global__ void k_quantize_nodes(const rtbvh::Node4* __restrict__ nodes, uint32_t n, float4* __restrict__ qnodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rtbvh::Node4 nd = nodes[i];
+    float lo[3] = {RT_INF, RT_INF, RT_INF}, hi[3] = {-RT_INF, -RT_INF, -RT_INF};
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+        if (nd.c[k].ref == EMPTY) continue;
+        bool finite = true;
+        for (int a = 0; a < 3; ++a) finite = finite && __builtin_fabsf(nd.c[k].lo[a]) < RT_INF && __builtin_fabsf(nd.c[k].hi[a]) < RT_INF;
+        if (!finite) continue;
+        any = true;
+        for (int a = 0; a < 3; ++a) lo[a] = fminf(lo[a], nd.c[k].lo[a]), hi[a] = fmaxf(hi[a], nd.c[k].hi[a]);
+    }
+    uint32_t ref[4];
+    unsigned char q[24];
+    float origin[3] = {0.0f, 0.0f, 0.0f}, scale[3] = {0.0f, 0.0f, 0.0f};
+    float pad[3] = {0.0f, 0.0f, 0.0f};
+    if (any) {
+        for (int a = 0; a < 3; ++a) {
+            pad[a] = 7.62939453125e-6f * fmaxf(__builtin_fabsf(lo[a]), __builtin_fabsf(hi[a])) + 1e-20f;
+            origin[a] = lo[a] - 2.0f * pad[a];
+            scale[a] = ((hi[a] + 2.0f * pad[a]) - origin[a]) * (1.0f / 254.0f);   // 254 steps reach the far side: one to spare
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        bool use = any && nd.c[k].ref != EMPTY;
+        for (int a = 0; a < 3 && use; ++a) use = __builtin_fabsf(nd.c[k].lo[a]) < RT_INF && __builtin_fabsf(nd.c[k].hi[a]) < RT_INF;
+        ref[k] = use ? nd.c[k].ref : EMPTY;
+        for (int a = 0; a < 3; ++a) {
+            int ql = 255, qh = 0;
+            if (use) {
+                const float l = nd.c[k].lo[a] - pad[a], h = nd.c[k].hi[a] + pad[a];
+                ql = (int)floorf((l - origin[a]) / scale[a]);
+                ql = min(max(ql, 0), 255);
+                while (ql > 0 && __builtin_fmaf((float)ql, scale[a], origin[a]) > l) --ql;
+                qh = (int)ceilf((h - origin[a]) / scale[a]);
+                qh = min(max(qh, 0), 255);
+                while (qh < 255 && __builtin_fmaf((float)qh, scale[a], origin[a]) < h) ++qh;
+                // a corner the grid cannot reach (should not happen: 254 steps span the padded box)
+                if (__builtin_fmaf((float)ql, scale[a], origin[a]) > l || __builtin_fmaf((float)qh, scale[a], origin[a]) < h) ql = 0, qh = 255;
+            }
+            q[6 * k + a] = (unsigned char)ql;
+            q[6 * k + 3 + a] = (unsigned char)qh;
+        }
+    }
+    uint32_t w[6];
+    for (int j = 0; j < 6; ++j) w[j] = (uint32_t)q[4 * j] | ((uint32_t)q[4 * j + 1] << 8) | ((uint32_t)q[4 * j + 2] << 16) | ((uint32_t)q[4 * j + 3] << 24);
+    float4* out = qnodes + 4 * (size_t)i;
+    out[0] = make_float4(origin[0], origin[1], origin[2], scale[0]);
+    out[1] = make_float4(scale[1], scale[2], __uint_as_float(ref[0]), __uint_as_float(ref[1]));
+    out[2] = make_float4(__uint_as_float(ref[2]), __uint_as_float(ref[3]), __uint_as_float(w[0]), __uint_as_float(w[1]));
+    out[3] = make_float4(__uint_as_float(w[2]), __uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5]));
 }
 
 // Triangle records in tree-leaf order: record r holds triangle order[r] (a global id).
@@ -1596,8 +1729,10 @@ __global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams 
     const uint32_t x = tx * RT_TILE + mx, y = ty * RT_TILE + my;
     const bool inside = x < p.width && y < p.height;
 
+    uint2 stack_rest[LaneStack::REST];
     LaneStack stk;
     stk.lds = &s_stack[MODE > 0 ? threadIdx.x : 0];
+    stk.spill = stack_rest;
     LaneStats st;
     float ox, oy;
     sample_offset(p.grid, s, &ox, &oy);
@@ -3154,6 +3289,12 @@ hipError_t leaf_bounds(const float* d_verts, const uint32_t* d_tris, const uint3
     if (n_leaves == 0) return hipSuccess;
     hipLaunchKernelGGL(k_leaf_bounds, dim3(grid_for(n_leaves, 256)), dim3(256), 0, s, d_verts, d_tris, d_leaf_first,
                        n_leaves, d_leaf_bounds);
+    return hipGetLastError();
+}
+
+hipError_t quantize_nodes(const rtbvh::Node4* d_nodes, uint32_t n, float4* d_qnodes, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_quantize_nodes, dim3(grid_for(n, 256)), dim3(256), 0, s, d_nodes, n, d_qnodes);
     return hipGetLastError();
 }
 
