@@ -1057,16 +1057,15 @@ struct WalkLds {
     uint16_t keys[RT_WALK_LDS * 64];
 };
 struct WalkStack {
-    uint32_t* refs;  // &lds.refs[lane]; entry e at refs[e * 64]
-    uint16_t* keys;
+    WalkLds* lds;    // the wave's block (wave-uniform); entry e of this lane at [e * 64 + threadIdx.x]
     uint2* spill;    // RT_STACK_MAX - RT_WALK_LDS entries of the caller's, in private memory. (An array inside
-                     // this struct would drag sp and the two pointers into private memory with it: every
-                     // push and pop then goes through scratch loads and untyped stores.)
+                     // this struct would drag sp into private memory with it: every push and pop then
+                     // goes through scratch loads.)
     int sp;
     __device__ __forceinline__ void push(uint32_t node, float tnear) {
         if (sp < RT_WALK_LDS) {
-            refs[sp * 64] = node;
-            keys[sp * 64] = (uint16_t)(__float_as_uint(tnear) >> 16);
+            lds->refs[sp * 64 + threadIdx.x] = node;
+            lds->keys[sp * 64 + threadIdx.x] = (uint16_t)(__float_as_uint(tnear) >> 16);
         } else if (sp < RT_STACK_MAX) {
             spill[sp - RT_WALK_LDS] = make_uint2(node, __float_as_uint(tnear));
         }
@@ -1074,7 +1073,7 @@ struct WalkStack {
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
-        if (sp < RT_WALK_LDS) return make_uint2(refs[sp * 64], (uint32_t)keys[sp * 64] << 16);
+        if (sp < RT_WALK_LDS) return make_uint2(lds->refs[sp * 64 + threadIdx.x], (uint32_t)lds->keys[sp * 64 + threadIdx.x] << 16);
         return spill[sp - RT_WALK_LDS];
     }
 };
@@ -1086,8 +1085,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
     uint2 stack_rest[RT_STACK_MAX - RT_WALK_LDS];
     WalkStack stk;
     stk.spill = stack_rest;
-    stk.refs = &s_stack.refs[threadIdx.x];
-    stk.keys = &s_stack.keys[threadIdx.x];
+    stk.lds = &s_stack;
     stk.sp = 0;
     bool has = false, walking = false, in_obj = false;
     bool exhausted = false;  // wave-uniform: the counter has passed the last ray
@@ -1097,7 +1095,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
     uint32_t turn = 0;
     uint32_t j = 0, oi = 0, cur = 0, local_best = 0;
     rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 1.0f), inv = d;
-    float nox = 0.0f, noy = 0.0f, noz = 0.0f, closest = RT_INF;
+    float closest = RT_INF;
     HitD hit;
     hit.tri = RT_MISS;
     hit.obj = 0;
@@ -1136,9 +1134,6 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                     in_obj = false;
                     oi = 0;
                     inv = g_recip(d);
-                    nox = -(o.x * inv.x);
-                    noy = -(o.y * inv.y);
-                    noz = -(o.z * inv.z);
                     closest = RT_INF;
                     hit.tri = RT_MISS;
                     hit.obj = 0;
@@ -1226,6 +1221,9 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             bool need_pop = true;
             if (!(cur & LEAF_BIT)) {
                 uint32_t next;
+                // -(o * inv) is worked out here rather than kept per ray: three registers fewer to hold
+                // through the whole walk (they were spilled), for three multiplications per step.
+                const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
 #if RT_WALK_QNODES
                 const bool go = node_step_q<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next);
 #else
