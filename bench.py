@@ -105,10 +105,12 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
     # Unit = one scatter ray; one launch = the scatter rays of one frame (st["bounce_rays"] of them,
     # out of samples * 10 ray slots: samples that hit nothing cast none). Algorithmic bytes of a
     # launch: per slot a 24-byte record out (hit point + id 16, state 4, sort key 4), per sample
-    # its 20-byte record in, plus the 4-wide tree, the triangle records and the normals / colours once.
+    # its 20-byte record in, plus the 4-wide tree (in the 64-byte form of its nodes that this walk reads:
+    # half of sizes["nodes4"]), the triangle records and the normals / colours once.
     samples = W * H * 4
     slots = samples * 10
-    alg_bytes = 24 * slots + 20 * samples + sizes["nodes4"] + sizes["recs"] + sizes["tri_data"]
+    nodes_compact = sizes["nodes4"] // 2
+    alg_bytes = 24 * slots + 20 * samples + nodes_compact + sizes["recs"] + sizes["tri_data"]
     flops = FLOP_BOX * st["bounce_box_tests"] + FLOP_TRI * st["bounce_tri_tests"]
     sec = bounce_ms * 1e-3
     return {
@@ -129,7 +131,7 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
         "frac": alg_bytes / sec / HBM_PEAK,
         "traffic": None,
         "alg_bytes_per_launch": alg_bytes,
-        "alg_bytes_parts": {"samples": samples, "ray_slots": slots, "nodes4": sizes["nodes4"], "recs": sizes["recs"],
+        "alg_bytes_parts": {"samples": 20 * samples, "ray_slots": 24 * slots, "nodes4_compact": nodes_compact, "recs": sizes["recs"],
                             "tri_data": sizes["tri_data"]},
         "requested_bytes_per_launch": st["bounce_fetch_bytes"],
         "requested_tb_per_s": st["bounce_fetch_bytes"] / sec / 1e12,

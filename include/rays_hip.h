@@ -131,8 +131,9 @@ void rt_scene_destroy(rt_scene*);
 /* Total triangle count (the hit-id space). */
 uint32_t rt_scene_num_tris(const rt_scene*);
 /* Device bytes of the scene's arrays: sizes[0] = wide tree (32 B per child), [1] = 4-wide tree
- * (128 B per node), [2] = triangle records in tree order (48 B per triangle), [3] = normals and
- * colours (24 B per triangle). For measurement; no reference counterpart. */
+ * (128 B per node; the persistent per-lane walk reads a 64-byte form of the same nodes, kept beside
+ * it: another half of this figure), [2] = triangle records in tree order (48 B per triangle),
+ * [3] = normals and colours (24 B per triangle). For measurement; no reference counterpart. */
 int  rt_scene_sizes(const rt_scene*, uint64_t sizes[4]);
 /* optimize_model's permutation for one object: order[i] = input position of the triangle at
  * sorted position i (src/opt.rs:12-35). */
