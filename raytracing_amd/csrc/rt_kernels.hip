@@ -2571,10 +2571,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ coun
 #ifndef RT_RTILE_GROUP
 #define RT_RTILE_GROUP 1
 #endif
+#ifndef RT_RUN
+#define RT_RUN 16u  // longest run of samples queued as one entry (a longer span of a row is queued in pieces)
+#endif
 struct RasterTileLds {
     unsigned long long z[RT_RTILE * RT_RTILE];   // nearest (t, id) per sample of the tile, row by row
     float tri[RT_RTILE_GROUP][RT_RTILE_TRIS][12];    // per wave: e1 xyz, e2 xyz, v0 xyz, id, object word, -
     uint32_t queue[RT_RTILE_GROUP][RT_RASTER_QUEUE]; // per wave: runs of candidate samples: first sample | length << 10 | slot << 16
+    uint16_t samples[RT_RTILE_GROUP][64 * RT_RUN];   // per wave: the samples of up to 64 runs, packed: sample | slot << 10
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
 };
 // Orders a wave's own LDS writes before its later LDS reads (the hardware serves one wave's LDS
@@ -2584,10 +2588,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-#ifndef RT_RUN
-#define RT_RUN 8u   // samples per queued run: a wave tests 64 / RT_RUN runs at a time
-#endif
-#define RT_RUNS_PER_TEST (64u / RT_RUN)
 
 // Position (subx, suby) of sub-sample s on the n x n grid inside a pixel: the inverse of sample_of.
 __device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t s, uint32_t* subx, uint32_t* suby) {
@@ -2688,27 +2688,53 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
 
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform: runs wait at queue[(q_head .. q_tail) % RT_RASTER_QUEUE]
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f);
-    // Puts the samples of up to 16 waiting runs through the exact test: the reference's arithmetic on
-    // the reference's ray, acceptance rule !failed && t > 0 (src/main.rs:117), then the object's box
-    // test; the nearest (t, id) of a sample is kept with an atomic minimum in LDS.
+    // Puts the samples of the first n (<= 64) waiting runs through the exact test: the reference's
+    // arithmetic on the reference's ray, acceptance rule !failed && t > 0 (src/main.rs:117), then the
+    // object's box test; the nearest (t, id) of a sample is kept with an atomic minimum in LDS. The
+    // runs are short (a triangle's row span averages under four samples), so they are first laid out
+    // sample by sample (a prefix sum of the runs' lengths over the lanes says where each run's samples
+    // go) and the test then takes 64 samples at a time whatever runs they came from: full waves in the
+    // division-carrying part instead of lanes reserved for the longest possible run.
     auto test_runs = [&](uint32_t n) {
-        const uint32_t e = lds.queue[wv][(q_head + min(lane / RT_RUN, n - 1u)) % RT_RASTER_QUEUE];
-        q_head += n;
-        const uint32_t j = lane % RT_RUN;
-        if (lane / RT_RUN >= n || j >= ((e >> 10) & 63u)) return;
-        const uint32_t zi = (e & 1023u) + j;
-        const float* td = lds.tri[wv][e >> 16];
-        const rt_f3 e1 = f3(td[0], td[1], td[2]), e2 = f3(td[3], td[4], td[5]), v0 = f3(td[6], td[7], td[8]);
-        const uint32_t id = __float_as_uint(td[9]), ow = __float_as_uint(td[10]);
-        const rt_f3 d = f3(lds.dx[zi & (RT_RTILE - 1u)], lds.dy[zi / RT_RTILE], 1.0f);
-        if (STATS) st.tri += 1;
-        const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
-        if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) return;
-        if (!(ow & 0x80000000u)) {
-            if (STATS) st.box += 1, st.bytes += 16;
-            if (!raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + (zi & (RT_RTILE - 1u)), (uint32_t)sw0 + zi / RT_RTILE)) return;
+        uint32_t e = 0, len = 0;
+        if (lane < n) {
+            e = lds.queue[wv][(q_head + lane) % RT_RASTER_QUEUE];
+            len = (e >> 10) & 63u;
         }
-        atomicMin(&lds.z[zi], ((unsigned long long)__float_as_uint(ev.t) << 32) | id);
+        q_head += n;
+        uint32_t incl = len;   // inclusive sum of the lengths over the lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += v;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t at = incl - len, code0 = (e & 1023u) | ((e >> 16) << 10);
+#pragma unroll
+        for (uint32_t j = 0; j < RT_RUN; ++j) {
+            if (j >= 4u && __ballot(j < len) == 0ull) break;   // most runs are short
+            if (j < len) lds.samples[wv][at + j] = (uint16_t)(code0 + j);
+        }
+        wave_lds_sync();
+        for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
+            const uint32_t g = g0 + lane;
+            if (g >= total) continue;
+            const uint32_t code = lds.samples[wv][g];
+            const uint32_t zi = code & 1023u;
+            const float* td = lds.tri[wv][code >> 10];
+            const rt_f3 e1 = f3(td[0], td[1], td[2]), e2 = f3(td[3], td[4], td[5]), v0 = f3(td[6], td[7], td[8]);
+            const uint32_t id = __float_as_uint(td[9]), ow = __float_as_uint(td[10]);
+            const rt_f3 d = f3(lds.dx[zi & (RT_RTILE - 1u)], lds.dy[zi / RT_RTILE], 1.0f);
+            if (STATS) st.tri += 1;
+            const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+            if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
+            if (!(ow & 0x80000000u)) {
+                if (STATS) st.box += 1, st.bytes += 16;
+                if (!raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + (zi & (RT_RTILE - 1u)), (uint32_t)sw0 + zi / RT_RTILE)) continue;
+            }
+            atomicMin(&lds.z[zi], ((unsigned long long)__float_as_uint(ev.t) << 32) | id);
+        }
+        wave_lds_sync();   // the next call lays its samples out over these
     };
 
     // Column of image-plane x: dx = (column + 0.5) / ax - aspect up to rounding, so a half-plane's
@@ -2769,14 +2795,14 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                 q_tail += (uint32_t)__builtin_popcountll(pm);
                 if (q_tail - q_head >= 64u) {
                     wave_lds_sync();
-                    while (q_tail - q_head >= RT_RUNS_PER_TEST) test_runs(RT_RUNS_PER_TEST);
+                    while (q_tail - q_head >= 64u) test_runs(64u);
                     wave_lds_sync();
                 }
             }
         }
         // The triangle slots are reused by the next 64 triangles: test what still waits.
         wave_lds_sync();
-        while (q_tail != q_head) test_runs(min(q_tail - q_head, RT_RUNS_PER_TEST));
+        while (q_tail != q_head) test_runs(min(q_tail - q_head, 64u));
         wave_lds_sync();
     }
 
