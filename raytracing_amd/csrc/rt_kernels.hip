@@ -2571,6 +2571,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ coun
 #ifndef RT_RTILE_GROUP
 #define RT_RTILE_GROUP 1
 #endif
+#ifndef RT_SEG
+#define RT_SEG 4u    // rows of a triangle's box that one lane goes down
+#endif
 #ifndef RT_RUN
 #define RT_RUN 16u  // longest run of samples queued as one entry (a longer span of a row is queued in pieces)
 #endif
@@ -2579,6 +2582,7 @@ struct RasterTileLds {
     float tri[RT_RTILE_GROUP][RT_RTILE_TRIS][12];    // per wave: e1 xyz, e2 xyz, v0 xyz, id, object word, -
     uint32_t queue[RT_RTILE_GROUP][RT_RASTER_QUEUE]; // per wave: runs of candidate samples: first sample | length << 10 | slot << 16
     uint16_t samples[RT_RTILE_GROUP][64 * RT_RUN];   // per wave: the samples of up to 64 runs, packed: sample | slot << 10
+    uint16_t segs[RT_RTILE_GROUP][64 * (RT_RTILE / RT_SEG)];   // per wave: row segments of the current 64 triangles: lane | segment << 6
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
 };
 // Orders a wave's own LDS writes before its later LDS reads (the hardware serves one wave's LDS
@@ -2762,41 +2766,76 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             td[10] = c.w;
         }
         if (base + RT_RTILE_TRIS * RT_RTILE_GROUP < n_list) cur = fetch(base + RT_RTILE_TRIS * RT_RTILE_GROUP);
+        // The triangles' boxes differ in height (ten rows on average, up to the tile's 32), so a wave in
+        // which every lane went down its own triangle's rows would run as long as its tallest triangle
+        // with a third of its lanes at work. The rows are dealt out in segments of RT_SEG instead: a
+        // prefix sum of the triangles' segment counts says which lane takes which segment, and the lane
+        // fetches that triangle's half-planes and box from the lane that set it up.
+        const uint32_t h = r1 >= r0 ? (uint32_t)(r1 - r0 + 1) : 0u;
+        const uint32_t nseg = (h + RT_SEG - 1u) / RT_SEG;
+        uint32_t seg_incl = nseg;
+#pragma unroll
+        for (int off2 = 1; off2 < 64; off2 <<= 1) {
+            const uint32_t v = __shfl_up(seg_incl, off2, 64);
+            if ((int)lane >= off2) seg_incl += v;
+        }
+        const uint32_t n_segs = (uint32_t)__builtin_amdgcn_readlane((int)seg_incl, 63);
+        {
+            const uint32_t at = seg_incl - nseg;
+#pragma unroll
+            for (uint32_t k = 0; k < RT_RTILE / RT_SEG; ++k)
+                if (k < nseg) lds.segs[wv][at + k] = (uint16_t)(lane | (k << 6));
+        }
+        const uint32_t box_word = (uint32_t)c0 | ((uint32_t)max(c1, 0) << 5) | ((uint32_t)r0 << 10) | ((uint32_t)max(r1, 0) << 15);
+        wave_lds_sync();
         // slope and offset of the boundary column as a function of the row's r = fma(dy, gy, gz)
         const float off = (aspect * ax - 0.5f) - (float)su0;
-        const float ku = -ax * __builtin_amdgcn_rcpf(rs.gu.x), kv = -ax * __builtin_amdgcn_rcpf(rs.gv.x),
-                    kw = -ax * __builtin_amdgcn_rcpf(rs.gw.x);
-        wave_lds_sync();
-        // Every lane goes down the rows of its own triangle: per row, the run of columns that pass
-        // all three half-planes (an exact run: see row_clip), queued in pieces of RT_RUN samples.
-        for (int row = r0; __ballot(row <= r1) != 0ull; ++row) {
-            int lo = c0, hi = row <= r1 ? c1 : c0 - 1;
-            if (lo <= hi) {
-                if (STATS) st.node += 1;
-                const float dy = lds.dy[row];
-                const float ru = __builtin_fmaf(dy, rs.gu.y, rs.gu.z), rv = __builtin_fmaf(dy, rs.gv.y, rs.gv.z),
-                            rw = __builtin_fmaf(dy, rs.gw.y, rs.gw.z);
-                row_clip(rs.gu.x, __builtin_fmaf(ru, ku, off), lo, hi);
-                row_clip(rs.gv.x, __builtin_fmaf(rv, kv, off), lo, hi);
-                row_clip(rs.gw.x, __builtin_fmaf(rw, kw, off), lo, hi);
-                // a half-plane that does not depend on the column passes the whole row or none of it
-                if ((rs.gu.x == 0.0f && ru < 0.0f) || (rs.gv.x == 0.0f && rv < 0.0f) || (rs.gw.x == 0.0f && rw < 0.0f)) hi = lo - 1;
-            }
-            while (true) {
-                const bool has = lo <= hi;
-                const unsigned long long pm = __ballot(has);
-                if (pm == 0ull) break;
-                if (has) {
-                    const uint32_t len = min((uint32_t)(hi - lo + 1), RT_RUN);
-                    const uint32_t pos = q_tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                    lds.queue[wv][pos % RT_RASTER_QUEUE] = ((uint32_t)row * RT_RTILE + (uint32_t)lo) | (len << 10) | (lane << 16);
-                    lo += (int)RT_RUN;
+        for (uint32_t g0 = 0; g0 < n_segs; g0 += 64u) {
+            const bool has_seg = g0 + lane < n_segs;
+            const uint32_t code = has_seg ? lds.segs[wv][g0 + lane] : 0u;
+            const int t = (int)(code & 63u);          // the lane that holds the triangle, and its slot in lds.tri
+            const uint32_t sg = code >> 6;
+            RasterSetup q;
+            q.gu = f3(__shfl(rs.gu.x, t, 64), __shfl(rs.gu.y, t, 64), __shfl(rs.gu.z, t, 64));
+            q.gv = f3(__shfl(rs.gv.x, t, 64), __shfl(rs.gv.y, t, 64), __shfl(rs.gv.z, t, 64));
+            q.gw = f3(__shfl(rs.gw.x, t, 64), __shfl(rs.gw.y, t, 64), __shfl(rs.gw.z, t, 64));
+            const uint32_t bw2 = (uint32_t)__shfl((int)box_word, t, 64);
+            const int sc0 = (int)(bw2 & 31u), sc1 = (int)((bw2 >> 5) & 31u);
+            const int sr0 = (int)((bw2 >> 10) & 31u) + (int)(sg * RT_SEG);
+            const int sr1 = has_seg ? min((int)((bw2 >> 15) & 31u), sr0 + (int)RT_SEG - 1) : sr0 - 1;
+            const float ku = -ax * __builtin_amdgcn_rcpf(q.gu.x), kv = -ax * __builtin_amdgcn_rcpf(q.gv.x),
+                        kw = -ax * __builtin_amdgcn_rcpf(q.gw.x);
+            // Every lane goes down the rows of its segment: per row, the run of columns that pass all
+            // three half-planes (an exact run: see row_clip), queued in pieces of RT_RUN samples.
+            for (int row = sr0; __ballot(row <= sr1) != 0ull; ++row) {
+                int lo = sc0, hi = row <= sr1 ? sc1 : sc0 - 1;
+                if (lo <= hi) {
+                    if (STATS) st.node += 1;
+                    const float dy = lds.dy[row];
+                    const float ru = __builtin_fmaf(dy, q.gu.y, q.gu.z), rv = __builtin_fmaf(dy, q.gv.y, q.gv.z),
+                                rw = __builtin_fmaf(dy, q.gw.y, q.gw.z);
+                    row_clip(q.gu.x, __builtin_fmaf(ru, ku, off), lo, hi);
+                    row_clip(q.gv.x, __builtin_fmaf(rv, kv, off), lo, hi);
+                    row_clip(q.gw.x, __builtin_fmaf(rw, kw, off), lo, hi);
+                    // a half-plane that does not depend on the column passes the whole row or none of it
+                    if ((q.gu.x == 0.0f && ru < 0.0f) || (q.gv.x == 0.0f && rv < 0.0f) || (q.gw.x == 0.0f && rw < 0.0f)) hi = lo - 1;
                 }
-                q_tail += (uint32_t)__builtin_popcountll(pm);
-                if (q_tail - q_head >= 64u) {
-                    wave_lds_sync();
-                    while (q_tail - q_head >= 64u) test_runs(64u);
-                    wave_lds_sync();
+                while (true) {
+                    const bool has = lo <= hi;
+                    const unsigned long long pm = __ballot(has);
+                    if (pm == 0ull) break;
+                    if (has) {
+                        const uint32_t len = min((uint32_t)(hi - lo + 1), RT_RUN);
+                        const uint32_t pos = q_tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                        lds.queue[wv][pos % RT_RASTER_QUEUE] = ((uint32_t)row * RT_RTILE + (uint32_t)lo) | (len << 10) | ((uint32_t)t << 16);
+                        lo += (int)RT_RUN;
+                    }
+                    q_tail += (uint32_t)__builtin_popcountll(pm);
+                    if (q_tail - q_head >= 64u) {
+                        wave_lds_sync();
+                        while (q_tail - q_head >= 64u) test_runs(64u);
+                        wave_lds_sync();
+                    }
                 }
             }
         }
