@@ -179,7 +179,13 @@ int  rt_render(rt_scene*, const rt_render_params*, uint8_t* rgba8, uint32_t* hit
 /* Device-buffer form. With shard_count > 1, d_rgba8 is this shard's compact tile buffer of
  * rt_shard_tiles() tiles, each RT_TILE * RT_TILE * 4 bytes, in ascending tile id. The frames of one
  * scene share the scene's per-sample workspace: enqueue them on one stream, or order the streams
- * yourself; frames of different scenes may overlap. */
+ * yourself; frames of different scenes may overlap. The caller's buffers are written on `stream`
+ * only (by the frame's last kernel). Camera + shadow frames (no bounces) keep two frames in flight:
+ * the phases before that last kernel run on streams of the scene's own, on alternating sets of
+ * workspace, so that consecutive frames overlap on the GPU; they are ordered behind nothing on
+ * `stream` (they read the immutable scene and the parameters, which are copied at the call) and the
+ * last kernel waits for them. RAYS_HIP_FRAMES_IN_FLIGHT=1 in the environment keeps every phase on
+ * `stream` (needed under stream capture). */
 int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                       void* stream);
 /* As rt_render_device, and records the caller's hipEvent_t handles on the stream around the
@@ -188,7 +194,8 @@ int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint
  * kernel records [0] before and [1]..[4] after it. Frames with diffuse scattering also record [5]
  * before and [6] after the launches that trace the secondary rays (all levels of the frame's last
  * run of tiles; [3] then follows the shadow rays of those levels); other frames record [5] and
- * [6] together with [4]. For measurement; no reference counterpart. */
+ * [6] together with [4]. With two frames in flight [0]..[3] are recorded on the scene's own stream
+ * and the phases of consecutive frames overlap. For measurement; no reference counterpart. */
 int  rt_render_device_events(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                              void* stream, void* const* events, int n_events);
 /* As rt_render_device, from an instrumented build of the same kernels; synchronises and fills

@@ -244,8 +244,9 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
 int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
                   hipStream_t stream, void* const* events = nullptr, DevStats* primary_stats = nullptr,
                   bool* projected = nullptr, DevStats* bounce_stats = nullptr) {
+    hipStream_t ws = stream;   // where the phases before the resolve kernel run (see in_flight below)
     auto mark = [&](int k) -> hipError_t {
-        return events ? hipEventRecord((hipEvent_t)events[k], stream) : hipSuccess;
+        return events ? hipEventRecord((hipEvent_t)events[k], k <= 3 ? ws : stream) : hipSuccess;
     };
     uint32_t spp = 0;
     int rc = check_render_params(p, &spp);
@@ -324,14 +325,30 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         run_tiles = (uint32_t)std::min<size_t>(dp.n_tiles, std::max<size_t>(1, cap / per_tile));
     }
     const size_t run_slots = (size_t)run_tiles * tile_slots;
-    rc = ensure_work(s->work, run_slots, stream);
+    // Two frames in flight: see rt_scene. Not for instrumented frames (their counters are read back
+    // between the phases); RAYS_HIP_FRAMES_IN_FLIGHT=1 keeps every frame on the caller's stream.
+    const char* fif = std::getenv("RAYS_HIP_FRAMES_IN_FLIGHT");   // read per call: the benchmark times both ways
+    const bool one_in_flight = fif && std::atoi(fif) == 1;
+    const bool in_flight = mode == 0 && run_tiles == dp.n_tiles && !d_stats && !primary_stats && !one_in_flight;
+    const int set = in_flight ? (int)(s->pipe_frames++ & 1u) : 0;
+    FrameWork& w = set ? s->work_b : s->work;
+    rc = ensure_work(w, run_slots, stream);
     if (rc != RT_OK) return rc;
     if (mode == 2) {
         rc = ensure_work(s->bounce_work, run_slots * tr.branches * tr.levels, stream);
         if (rc != RT_OK) return rc;
     }
-    FrameWork& w = s->work;
     FrameWork& bw = s->bounce_work;
+    if (in_flight) {
+        if (!s->pipe_stream[set]) {
+            HIP_TRY(hipStreamCreateWithFlags(&s->pipe_stream[set], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&s->pipe_ready[set], hipEventDisableTiming));
+        }
+        ws = s->pipe_stream[set];
+    }
+    if (!s->pipe_free[set]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_free[set], hipEventDisableTiming));
+    // The buffers of this set are free once the resolve kernel of the frame that used them last is done.
+    if (in_flight && s->pipe_free_set[set]) HIP_TRY(hipStreamWaitEvent(ws, s->pipe_free[set], 0));
     // Camera rays by projection, unless a triangle would cover more than 16384 blocks of 8 x 8 samples
     // (one wave steps over a triangle's blocks) or the frame is taller than wide (aspect 0).
     bool raster = s->raster_ok && p->width >= p->height && p->width / p->height <= 4 &&
@@ -395,12 +412,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             w.bin_recs_tris = n_packed;
         }
         HIP_TRY(rtk::raster_bin(s->view, dp, n_packed, w.cam_table, n_rt, w.bin_counts, w.bin_offsets, w.bin_list,
-                                (uint32_t)w.bin_capacity, w.bin_recs, false, stream));
+                                (uint32_t)w.bin_capacity, w.bin_recs, false, ws));
         const uint32_t key[5] = {p->width, p->height, p->grid, p->shard_index, p->shard_count};
         if (!w.bin_list || std::memcmp(key, w.bin_key, sizeof(key)) != 0) {
             // First frame of this shape: the lists' total length, read back once.
             uint32_t total = 0;
-            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipStreamSynchronize(ws));
             HIP_TRY(hipMemcpy(&total, w.bin_offsets + n_rt, 4, hipMemcpyDeviceToHost));
             if (w.bin_capacity < total || !w.bin_list) {
                 if (w.bin_list) (void)hipFree(w.bin_list);
@@ -412,7 +429,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             std::memcpy(w.bin_key, key, sizeof(key));
         }
         HIP_TRY(rtk::raster_bin(s->view, dp, n_packed, w.cam_table, n_rt, w.bin_counts, w.bin_offsets, w.bin_list,
-                                (uint32_t)w.bin_capacity, w.bin_recs, true, stream));
+                                (uint32_t)w.bin_capacity, w.bin_recs, true, ws));
     } else if (raster) {
         const size_t words = (size_t)p->width * p->height * spp;
         if (w.zbuf_words < words) {
@@ -425,7 +442,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         }
         const bool clear = !w.zbuf_clean;
         w.zbuf_clean = false;  // until the record pass has been through every tile of this frame
-        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, clear, d_stats, stream));
+        HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, clear, d_stats, ws));
     }
     for (uint32_t first = 0; first < total_tiles; first += run_tiles) {
         const bool last_run = first + run_tiles >= total_tiles;
@@ -435,24 +452,28 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const LightProj lp = light_projection(s, p, n_slots);
         if (raster_by_tile) {
             HIP_TRY(rtk::raster_tiles(s->view, dp, lp, d_list, w.cam_table, w.bin_offsets, w.bin_list, w.bin_recs, w.samp,
-                                      w.state, w.keys[0], d_stats, stream));
+                                      w.state, w.keys[0], d_stats, ws));
         } else if (raster) {
-            HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], d_stats, stream));
+            HIP_TRY(rtk::raster_records(s->view, dp, lp, d_list, w.zbuf, w.samp, w.state, w.keys[0], d_stats, ws));
         } else {
-            HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, stream));
+            HIP_TRY(rtk::wf_primary(s->view, dp, lp, d_list, w.samp, w.state, w.keys[0], d_stats, ws));
         }
         if (last_run) HIP_TRY(mark(1));
         if (primary_stats && d_stats && last_run) {
-            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipStreamSynchronize(ws));
             HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
         }
         size_t tb = w.temp_bytes;
-        HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], nullptr, w.order, n_slots, lp.key_bits, stream));
+        HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], nullptr, w.order, n_slots, lp.key_bits, ws));
         if (last_run) HIP_TRY(mark(2));
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
-                               w.order, w.samp, w.state, d_stats, stream));
+                               w.order, w.samp, w.state, d_stats, ws));
         if (mode == 0) {
             if (last_run) HIP_TRY(mark(3));
+            if (in_flight) {
+                HIP_TRY(hipEventRecord(s->pipe_ready[set], ws));
+                HIP_TRY(hipStreamWaitEvent(stream, s->pipe_ready[set], 0));
+            }
             HIP_TRY(rtk::wf_resolve(s->view, dp, d_list, w.samp, w.state, d_rgba8, d_hit_ids, stream));
         } else {
             tr.level_rays = (uint32_t)(n_slots * tr.branches);
@@ -507,6 +528,8 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         HIP_TRY(mark(6));
     }
     if (raster && !raster_by_tile) w.zbuf_clean = true;
+    HIP_TRY(hipEventRecord(s->pipe_free[set], stream));
+    s->pipe_free_set[set] = true;
     return RT_OK;
 }
 

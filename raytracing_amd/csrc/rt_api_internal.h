@@ -98,6 +98,17 @@ struct rt_scene {
     rt_ctx* ctx = nullptr;
     FrameWork work;         // per sample: camera rays and their shadow rays
     FrameWork bounce_work;  // per scatter ray of a run of tiles
+    // Two frames in flight (camera + shadow frames that run as one piece): consecutive frames alternate
+    // between `work` and `work_b` and between two streams of the scene's own, on which everything up to
+    // the shadow kernel runs; only the resolve kernel, which writes the caller's buffer, runs on the
+    // caller's stream. A frame's memory-bound phases then overlap the next frame's compute-bound ones.
+    // pipe_ready[b]: the shadow kernel of the frame in set b is done. pipe_free[b]: the resolve kernel
+    // that read set b is done (recorded on the caller's stream).
+    FrameWork work_b;
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipEvent_t pipe_ready[2] = {nullptr, nullptr}, pipe_free[2] = {nullptr, nullptr};
+    bool pipe_free_set[2] = {false, false};
+    uint64_t pipe_frames = 0;
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
     // Camera rays by projection (the camera of src/main.rs:314-330 stands at the origin and looks along
     // +z): possible when no object has trailing triangles and every triangle lies in front of the
@@ -117,7 +128,16 @@ struct rt_scene {
     std::vector<DevObject> objects;
     std::vector<std::vector<uint32_t>> order;  // per object: sorted position -> input position
     ~rt_scene() {
+        for (int b = 0; b < 2; ++b) {
+            if (pipe_stream[b]) {
+                (void)hipStreamSynchronize(pipe_stream[b]);
+                (void)hipStreamDestroy(pipe_stream[b]);
+            }
+            if (pipe_ready[b]) (void)hipEventDestroy(pipe_ready[b]);
+            if (pipe_free[b]) (void)hipEventDestroy(pipe_free[b]);
+        }
         work.release();
+        work_b.release();
         bounce_work.release();
         for (void* p : device_ptrs) (void)hipFree(p);
     }
