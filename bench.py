@@ -195,10 +195,26 @@ def main():
     comm = None
     ranks_seen = 1
     if world > 1 and backend == "nccl":
-        box = [comm_id_create() if rank == 0 else None]
+        # If the library cannot bring up its communicator on every rank (RCCL not loadable, say), the
+        # ranks agree to gather through torch.distributed instead; the bench line says which it was.
+        try:
+            box = [comm_id_create() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: rt_comm_id_create failed: {e}", file=sys.stderr)
+            box = [None]
         dist.broadcast_object_list(box, src=0)
-        comm = Comm(ctx, box[0], rank, world)
-        ranks_seen = comm.ranks()[1]
+        if box[0] is not None:
+            try:
+                comm = Comm(ctx, box[0], rank, world)
+                ranks_seen = comm.ranks()[1]
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: rank {rank}: rt_comm_create failed: {e}", file=sys.stderr)
+                comm = None
+        agreed = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
 
     p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0,
                       shard_index=rank, shard_count=world)
@@ -263,6 +279,12 @@ def main():
             if comm is not None:
                 comm.gather_tiles_device(frames[b].data_ptr(), W, H, full.data_ptr() if rank == 0 else None,
                                          comm_stream.cuda_stream)
+            elif backend == "nccl":
+                gathered, _ = rd.gather_slabs(frames[b], slab_bytes, dst=0)
+                if rank == 0:
+                    ctx.deinterleave_device(gathered.data_ptr(), slab, W, H, world, full.data_ptr(),
+                                            comm_stream.cuda_stream)
+                    gathered.record_stream(comm_stream)
             else:
                 host, _ = rd.gather_slabs(frames[b].cpu(), slab_bytes, dst=0)
                 if rank == 0:
@@ -407,7 +429,8 @@ def main():
                 "sharded_frame_equals_whole_frame": frame_ok,
                 "backend": backend if world > 1 else None,
                 "gather": ("rt_gather_tiles_device (RCCL send/recv to rank 0)" if comm is not None else
-                           ("host-staged rehearsal" if world > 1 else None)),
+                           (("torch.distributed.gather over RCCL (the library's communicator did not come up)"
+                             if backend == "nccl" else "host-staged rehearsal") if world > 1 else None)),
                 "ranks_seen": ranks_seen,
             },
             "roofline": {
