@@ -184,6 +184,8 @@ int ensure_work(FrameWork& w, size_t n, hipStream_t stream) {
     HIP_TRY(hipMalloc((void**)&w.counts, (RT_MAX_REFLECT + 1) * 4));
     HIP_TRY(hipMalloc(&w.temp, std::max<size_t>(tb, 16)));
     w.temp_bytes = tb;
+    HIP_TRY(hipMalloc(&w.radix_work, std::max<size_t>(rtk::radix_workspace_bytes(n), 16)));
+    HIP_TRY(hipMalloc((void**)&w.n_valid, 256));
     w.capacity = n;
     return RT_OK;
 }
@@ -463,11 +465,18 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(hipStreamSynchronize(ws));
             HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
         }
-        size_t tb = w.temp_bytes;
-        HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], nullptr, w.order, n_slots, lp.key_bits, ws));
+        // The library's own sort moves the keys that carry a shadow ray only and leaves their number on
+        // the device; RAYS_HIP_SORT=rocprim sorts all of them with the library sort instead.
+        const bool own_sort = !env_is("RAYS_HIP_SORT", 'r');
+        if (own_sort) {
+            HIP_TRY(rtk::radix_sort_valid(w.radix_work, w.keys[0], w.keys[1], w.order, n_slots, lp.key_bits, w.n_valid, ws));
+        } else {
+            size_t tb = w.temp_bytes;
+            HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], nullptr, w.order, n_slots, lp.key_bits, ws));
+        }
         if (last_run) HIP_TRY(mark(2));
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
-                               w.order, w.samp, w.state, d_stats, ws));
+                               w.order, w.samp, w.state, d_stats, ws, own_sort ? w.n_valid : nullptr));
         if (mode == 0) {
             if (last_run) HIP_TRY(mark(3));
             if (in_flight) {
@@ -512,11 +521,17 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 bounce_stats->node_visits += after.node_visits - before_bounce.node_visits;
                 bounce_stats->fetch_bytes += after.fetch_bytes - before_bounce.fetch_bytes;
             }
-            size_t tb2 = bw.temp_bytes;
-            HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], nullptr, bw.order, n_rays,
-                                        lp2.key_bits, stream));
+            if (own_sort) {
+                HIP_TRY(rtk::radix_sort_valid(bw.radix_work, bw.keys[0], bw.keys[1], bw.order, n_rays, lp2.key_bits,
+                                              bw.n_valid, stream));
+            } else {
+                size_t tb2 = bw.temp_bytes;
+                HIP_TRY(rtk::sort_pairs_u32(bw.temp, &tb2, bw.keys[0], bw.keys[1], nullptr, bw.order, n_rays,
+                                            lp2.key_bits, stream));
+            }
             HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_rays, lp2.key_bits > 16 ? lp2.key_bits - 16 : 0u,
-                                   bw.keys[1], bw.order, bw.samp, bw.state, d_stats, stream));
+                                   bw.keys[1], bw.order, bw.samp, bw.state, d_stats, stream,
+                                   own_sort ? bw.n_valid : nullptr));
             if (last_run) HIP_TRY(mark(3));
             HIP_TRY(rtk::wf_resolve_tree(s->view, dp, tr, d_list, w.samp, w.state, bw.samp, bw.state, d_rgba8,
                                          d_hit_ids, stream));

@@ -86,9 +86,11 @@ struct FrameWork {
     uint32_t bin_key[5] = {0, 0, 0, 0, 0};   // width, height, grid, shard_index, shard_count
     void* temp = nullptr;
     size_t temp_bytes = 0;
+    void* radix_work = nullptr;      // workspace of the library's own sort (rtk::radix_sort_valid)
+    uint32_t* n_valid = nullptr;     // device word: shadow rays among the sorted keys
     void release() {
         for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp,
-                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list, (void*)bin_recs})
+                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list, (void*)bin_recs, radix_work, (void*)n_valid})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }

@@ -54,7 +54,7 @@ hipError_t raster_tiles(const SceneView& sv, const DevRenderParams& p, const Lig
                         float4* d_samp, uint32_t* d_state, uint32_t* d_keys, DevStats* d_stats, hipStream_t s);
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                     DevStats* d_stats, hipStream_t s);
+                     DevStats* d_stats, hipStream_t s, const uint32_t* d_n_valid = nullptr);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
 // Diffuse and mirror bounces as a pipeline: one launch of wf_bounce per level of the tree of
@@ -72,6 +72,12 @@ hipError_t wf_resolve_tree(const SceneView& sv, const DevRenderParams& p, const 
                            hipStream_t s);
 // Stable radix sort of (u32 key, u32 value) pairs on the low key_bits bits of the key. With
 // temp == nullptr only *temp_bytes is set.
+// The library's own sort of the shadow rays' keys (rt_radix.hip): stable, on the low key_bits bits, of the
+// keys that are not all ones; values = the keys' positions in keys_in. keys_out / vals_out receive the
+// *d_n_valid sorted pairs; the count stays on the device. `work` = radix_workspace_bytes(n) bytes.
+size_t radix_workspace_bytes(size_t n);
+hipError_t radix_sort_valid(void* work, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, size_t n,
+                            unsigned key_bits, uint32_t* d_n_valid, hipStream_t s);
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                           const uint32_t* vals_in, uint32_t* vals_out, size_t n, unsigned key_bits, hipStream_t s);
 // Tree build on the device (rt_lbvh.hip). Sizes of the two trees over n single-triangle leaves:

@@ -2930,12 +2930,15 @@ __global__ __launch_bounds__(RT_WF_BLOCK, RT_SHADOW_WAVES) void k_wf_shadow(Scen
                                                         const uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals,
                                                         const float4* __restrict__ samp, uint32_t* __restrict__ state,
-                                                        DevStats* __restrict__ stats) {
+                                                        DevStats* __restrict__ stats,
+                                                        const uint32_t* __restrict__ n_valid) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
     const uint64_t i = (uint64_t)xcd_block(blockIdx.x) * RT_WF_BLOCK + threadIdx.x;
-    const bool act = i < n && keys[i] != 0xFFFFFFFFu;
-    if (__ballot(act) == 0ull) return;  // keys are sorted: samples without a shadow ray come last
+    // n_valid (the library's own sort): the first *n_valid keys carry a shadow ray, what follows is
+    // stale. Otherwise all n keys are sorted and those without a ray, all ones, come last.
+    const bool act = n_valid ? i < *n_valid : (i < n && keys[i] != 0xFFFFFFFFu);
+    if (__ballot(act) == 0ull) return;
     LaneStats st;
     const uint32_t slot = act ? vals[i] : 0u;
     const float4 a = samp[slot];
@@ -3469,15 +3472,15 @@ hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const L
 
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                     DevStats* d_stats, hipStream_t s) {
+                     DevStats* d_stats, hipStream_t s, const uint32_t* d_n_valid) {
     if (n == 0) return hipSuccess;
     const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
     if (d_stats)
         hipLaunchKernelGGL((k_wf_shadow<true>), dim3(xcd_grid(grid_for(n, RT_WF_BLOCK))), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
-                           d_vals, d_samp, d_state, d_stats);
+                           d_vals, d_samp, d_state, d_stats, d_n_valid);
     else
         hipLaunchKernelGGL((k_wf_shadow<false>), dim3(xcd_grid(grid_for(n, RT_WF_BLOCK))), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
-                           d_vals, d_samp, d_state, d_stats);
+                           d_vals, d_samp, d_state, d_stats, d_n_valid);
     return hipGetLastError();
 }
 
