@@ -21,9 +21,14 @@
 
 namespace {
 
+#ifndef RT_RADIX_BLOCK
 #define RT_RADIX_BLOCK 2048u     // keys per block (one wave): 32 rounds of 64
+#endif
 #define RT_RADIX_GROUP 256u      // blocks per group of the offset computation
 #define RT_RADIX_NONE 0xFFFFFFFFu
+#ifndef RT_RADIX_AHEAD
+#define RT_RADIX_AHEAD 4u        // rounds whose keys a wave loads before it works on them
+#endif
 
 __device__ __forceinline__ void radix_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -49,18 +54,31 @@ __global__ __launch_bounds__(64) void k_radix_hist(const uint32_t* __restrict__ 
     for (uint32_t k = lane; k < 256u; k += 64u) h[k] = 0u;
     radix_lds_sync();
     if (first < limit) {
-        for (uint32_t r = 0; r < RT_RADIX_BLOCK / 64u; r += 4u) {
-            uint32_t key[4];
+        // Counting does not care about the order: four keys a lane and load (16 bytes), two loads ahead.
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys + first);
+        for (uint32_t r = 0; r < RT_RADIX_BLOCK / 256u; r += 2u) {
+            uint4 q[2];
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t i = first + (r + j) * 64u + lane;
-                key[j] = i < limit ? keys[i] : RT_RADIX_NONE;
+            for (uint32_t j = 0; j < 2u; ++j) {
+                const uint32_t i = first + (r + j) * 256u + 4u * lane;
+                q[j] = make_uint4(RT_RADIX_NONE, RT_RADIX_NONE, RT_RADIX_NONE, RT_RADIX_NONE);
+                if (i + 3u < limit) {
+                    q[j] = k4[(r + j) * 64u + lane];
+                } else {
+                    if (i < limit) q[j].x = keys[i];
+                    if (i + 1u < limit) q[j].y = keys[i + 1u];
+                    if (i + 2u < limit) q[j].z = keys[i + 2u];
+                }
             }
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t i = first + (r + j) * 64u + lane;
-                const bool valid = i < limit && (!FIRST || key[j] != RT_RADIX_NONE);
-                if (valid) atomicAdd(&h[(key[j] >> shift) & 255u], 1u);
+            for (uint32_t j = 0; j < 2u; ++j) {
+                const uint32_t i = first + (r + j) * 256u + 4u * lane;
+                const uint32_t kk[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (uint32_t c = 0; c < 4u; ++c) {
+                    const bool valid = i + c < limit && (!FIRST || kk[c] != RT_RADIX_NONE);
+                    if (valid) atomicAdd(&h[(kk[c] >> shift) & 255u], 1u);
+                }
             }
         }
         radix_lds_sync();
@@ -135,16 +153,16 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint32_t* __restrict
     }
     radix_lds_sync();
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t r = 0; r < RT_RADIX_BLOCK / 64u; r += 4u) {
-        uint32_t key[4], val[4];
+    for (uint32_t r = 0; r < RT_RADIX_BLOCK / 64u; r += RT_RADIX_AHEAD) {
+        uint32_t key[RT_RADIX_AHEAD], val[RT_RADIX_AHEAD];
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
+        for (uint32_t j = 0; j < RT_RADIX_AHEAD; ++j) {
             const uint32_t i = first + (r + j) * 64u + lane;
             key[j] = i < limit ? keys[i] : RT_RADIX_NONE;
             val[j] = FIRST ? i : (i < limit ? vals[i] : 0u);
         }
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
+        for (uint32_t j = 0; j < RT_RADIX_AHEAD; ++j) {
             const uint32_t i = first + (r + j) * 64u + lane;
             const bool valid = i < limit && (!FIRST || key[j] != RT_RADIX_NONE);
             const unsigned long long any = __ballot(valid);
