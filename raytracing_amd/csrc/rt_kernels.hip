@@ -425,6 +425,34 @@ __device__ __forceinline__ void packet_leaf(const SceneView& sv, uint32_t ref, u
     }
 }
 
+// One leaf (wave-uniform reference) in shadow mode, with the wave's unoccluded rays kept as one
+// 64-bit mask instead of a flag per lane: every lane runs the test, a ballot says which rays the
+// triangle occludes, and the mask loses them. (Per-lane flags that change inside the walk's loops
+// cost a merge of three scalar instructions at every join of the control flow.)
+template <bool STATS>
+__device__ __forceinline__ void leaf_any(const SceneView& sv, uint32_t ref, rt_f3 o, rt_f3 d, unsigned long long& alive,
+                                         LaneStats& st) {
+    const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
+    const uint32_t n = (ref & 7u) + 1u;
+    const bool bounded = sv.scene_extent < 1.0e12f;   // see tri_head_fails
+    for (uint32_t i = 0; i < n; ++i) {
+        const char* rp = reinterpret_cast<const char*>(sv.recs) + 48 * (size_t)(first + i);
+        const f32x8_t ra = sload8(rp);
+        const f32x4_t rb = sload4(rp + 32);
+        const rt_f3 v0 = f3(ra[0], ra[1], ra[2]), e1 = f3(ra[3], ra[4], ra[5]), e2 = f3(ra[6], ra[7], rb[0]);
+        if (STATS) {
+            if ((alive >> (threadIdx.x & 63u)) & 1ull) st.tri += 1;
+            if ((threadIdx.x & 63u) == 0u) st.bytes += 48;
+        }
+        const rt_tri_head hd = tri_begin(e1, e2, v0, o, d);
+        if (RT_ANY_EARLY_OUT && bounded && (__ballot(!tri_head_fails(hd)) & alive) == 0ull) continue;
+        const rt_tri_eval ev = tri_finish(hd, e1, e2, d);
+        // src/main.rs:185-193: any lane whose t has a clear sign bit occludes
+        alive &= ~__ballot(!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t));
+        if (alive == 0ull) return;
+    }
+}
+
 // Walks one object's tree for the whole wave. `active` marks the lanes whose rays take part.
 // Acceptance rules are those of bvh_search.
 template <bool ANY, bool STATS>
@@ -714,6 +742,8 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     };
     float zc = ANY ? RT_INF : far_rel(closest);
     float wend_rel = ANY ? RT_INF : wave_max_f32(active ? zc : -RT_INF);
+    // Shadow mode keeps the rays still without an occluder as one mask (see leaf_any).
+    unsigned long long alive = ANY ? __ballot(active) : 0ull;
     int n_beam = __builtin_popcountll(__ballot(active));  // lanes the current beam was built from
     int level = 0;
     uint32_t key = 0xFFFFFFFFu, cref = 0;
@@ -739,7 +769,9 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
                 const int l = __builtin_ctzll(lm);
                 lm &= lm - 1ull;
                 if (ANY) {
-                    if (__ballot(active) == 0ull) break;
+                    if (alive == 0ull) break;
+                    leaf_any<STATS>(sv, (uint32_t)__builtin_amdgcn_readlane((int)cref, l), o, d, alive, st);
+                    continue;
                 } else {
                     const float kf = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)key, l) & ~63u);
                     if (__ballot(active && zc > kf) == 0ull) continue;
@@ -776,7 +808,7 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
         // Lanes that can still gain from pending children: all unoccluded lanes in shadow mode;
         // in nearest-hit mode those whose nearest hit lies beyond the next child's entry (the
         // walk is front to back along w, so the others are finished for this level).
-        const unsigned long long rel = ANY ? __ballot(active) : __ballot(active && zc > kf);
+        const unsigned long long rel = ANY ? alive : __ballot(active && zc > kf);
         if (ANY && rel == 0ull) {
             running = false;
         } else if (kmin == 0xFFFFFFFFu || (!ANY && rel == 0ull)) {
@@ -798,7 +830,7 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
             const int n_rel = __builtin_popcountll(rel);
             if (ANY && 2 * n_rel <= n_beam) {
                 BeamLane tmp;
-                make_beam<M>(sv, o, d, active, b, tmp, false);
+                make_beam<M>(sv, o, d, ((alive >> lane) & 1ull) != 0ull, b, tmp, false);
                 n_beam = n_rel;
                 if (STATS && lane == 0) st.walks[2] += 1;
             }
@@ -807,6 +839,7 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
             if (lane == sel) key = 0xFFFFFFFFu;
         }
     }
+    if (ANY && active && !((alive >> lane) & 1ull)) occluded = true;
     return true;
 }
 
