@@ -573,6 +573,30 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 #undef RT_DPP_REDUCE
+// Four reductions at once (minimum of a and c, maximum of b and d): the four chains are independent,
+// so each step's four instructions stand between a register's write and its next DPP read and no
+// wait states have to be spent on s_nop.
+#define RT_DPP4(STEP)                                     \
+    "v_min_f32_dpp %0, %0, %0 " STEP "\n\t"               \
+    "v_max_f32_dpp %1, %1, %1 " STEP "\n\t"               \
+    "v_min_f32_dpp %2, %2, %2 " STEP "\n\t"               \
+    "v_max_f32_dpp %3, %3, %3 " STEP "\n\t"
+__device__ __forceinline__ void wave_minmax4(float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1\n\t"
+                 RT_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 RT_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 RT_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 RT_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 RT_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RT_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+    c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+    d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+}
+#undef RT_DPP4
 
 // The beam of a wave, wave-uniform. Rays are written along their dominant axis w (the axis with
 // the largest direction component, mirrored so that every ray travels towards +w): on each of
@@ -648,20 +672,19 @@ __device__ __forceinline__ bool make_beam(const SceneView& sv, rt_f3 o, rt_f3 d,
         const float eA0 = (__builtin_fabsf(oa) + __builtin_fabsf(B0 * bl.ow)) * (4.0f * RT_MARGIN) + 1e-30f;
         const float eA1 = (__builtin_fabsf(ob) + __builtin_fabsf(B1 * bl.ow)) * (4.0f * RT_MARGIN) + 1e-30f;
         const bool use = active & lane_ok;
-        b.a0[0] = wave_min_f32(use ? A0 - eA0 : RT_INF);
-        b.a1[0] = wave_max_f32(use ? A0 + eA0 : -RT_INF);
-        b.b0[0] = wave_min_f32(use ? B0 - eB0 : RT_INF);
-        b.b1[0] = wave_max_f32(use ? B0 + eB0 : -RT_INF);
-        b.a0[1] = wave_min_f32(use ? A1 - eA1 : RT_INF);
-        b.a1[1] = wave_max_f32(use ? A1 + eA1 : -RT_INF);
-        b.b0[1] = wave_min_f32(use ? B1 - eB1 : RT_INF);
-        b.b1[1] = wave_max_f32(use ? B1 + eB1 : -RT_INF);
+        float q0 = use ? A0 - eA0 : RT_INF, q1 = use ? A0 + eA0 : -RT_INF, q2 = use ? B0 - eB0 : RT_INF,
+              q3 = use ? B0 + eB0 : -RT_INF;
+        wave_minmax4(q0, q1, q2, q3);
+        b.a0[0] = q0, b.a1[0] = q1, b.b0[0] = q2, b.b1[0] = q3;
+        q0 = use ? A1 - eA1 : RT_INF, q1 = use ? A1 + eA1 : -RT_INF, q2 = use ? B1 - eB1 : RT_INF,
+        q3 = use ? B1 + eB1 : -RT_INF;
+        wave_minmax4(q0, q1, q2, q3);
+        b.a0[1] = q0, b.a1[1] = q1, b.b0[1] = q2, b.b1[1] = q3;
     }
-    const float ws = wave_min_f32(active ? bl.ow : RT_INF);
+    float ws = active ? bl.ow : RT_INF, wf = active ? bl.ow : -RT_INF, ws2 = ws, wf2 = wf;
+    wave_minmax4(ws, wf, ws2, wf2);
     b.wstart = ws - __builtin_fabsf(ws) * RT_MARGIN;
-#if RT_ANY_PREFER_FAR
-    b.wfar = wave_max_f32(active ? bl.ow : -RT_INF);
-#endif
+    b.wfar = wf;
     if (first) b.wbase = b.wstart;
     // A beam much wider than the geometry it meets makes every lane test every triangle of a
     // large region (rays that happen to share a wave but not a neighbourhood): leave those waves
