@@ -220,14 +220,21 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
     lp.sun_w = p->sun[lp.w];
     lp.sun_a1 = p->sun[lp.a1];
     lp.sun_a2 = p->sun[lp.a2];
+    lp.c_w = c[lp.w];
+    lp.c_a1 = c[lp.a1];
+    lp.c_a2 = c[lp.a2];
+    const float cw = lp.c_w - lp.sun_w;
+    bool ok = std::fabs(cw) > 0.0f;
+    lp.uc = ok ? (lp.c_a1 - lp.sun_a1) / cw : 0.0f;
+    lp.vc = ok ? (lp.c_a2 - lp.sun_a2) / cw : 0.0f;
     float u0 = INFINITY, u1 = -INFINITY, v0 = INFINITY, v1 = -INFINITY;
-    bool ok = true;
     for (int corner = 0; corner < 8; ++corner) {
         float q[3];
         for (int k = 0; k < 3; ++k) q[k] = (corner >> k) & 1 ? s->bounds_hi[k] : s->bounds_lo[k];
         const float pw = q[lp.w] - lp.sun_w;
         if (!(std::fabs(pw) > 0.0f)) ok = false;
-        const float u = (q[lp.a1] - lp.sun_a1) / pw, v = (q[lp.a2] - lp.sun_a2) / pw;
+        const float dw = q[lp.w] - lp.c_w;
+        const float u = ((q[lp.a1] - lp.c_a1) - lp.uc * dw) / pw, v = ((q[lp.a2] - lp.c_a2) - lp.vc * dw) / pw;
         u0 = std::min(u0, u); u1 = std::max(u1, u);
         v0 = std::min(v0, v); v1 = std::max(v1, v);
     }
@@ -238,6 +245,8 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
     lp.v0 = ok ? v0 : 0.0f;
     lp.uscale = (ok && u1 > u0) ? 65535.0f / (u1 - u0) : 0.0f;  // 0: every ray gets the same key
     lp.vscale = (ok && v1 > v0) ? 65535.0f / (v1 - v0) : 0.0f;
+    lp.uabs = ok ? std::max(std::fabs(u0), std::fabs(u1)) : 0.0f;
+    lp.vabs = ok ? std::max(std::fabs(v0), std::fabs(v1)) : 0.0f;
     return lp;
 }
 
@@ -382,6 +391,57 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (projected) *projected = raster;
     const uint32_t total_tiles = dp.n_tiles;
     HIP_TRY(mark(0));
+    // The library's own sort moves the keys that carry a shadow ray only and leaves their number on
+    // the device; RAYS_HIP_SORT=rocprim sorts all of them with the library sort instead.
+    const bool own_sort = !env_is("RAYS_HIP_SORT", 'r');
+    // Shadow rays by light-space cells when the scene's triangles spread thinly enough over the
+    // light-space grid of the sort (decided on the device, from the lists' lengths; the tree walk
+    // takes the launch otherwise). Not worth the lists for small scenes, nor for scenes whose
+    // lists are bound to be long: about 4 n_tris / cells entries per cell. The lists depend on the
+    // scene and the sun only; they are built on a stream of their own beside the camera rays.
+    bool cells = false;
+    if (mode == 0 && own_sort) {
+        const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots);
+        const size_t lc_cells = (size_t)1 << lp.key_bits;
+        cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 20 && s->objects.size() <= 32 &&
+                s->n_tris_total >= 32768 && s->n_tris_total < (1u << 26) &&
+                (size_t)s->n_tris_total * 4 <= lc_cells * 256 && !env_is("RAYS_HIP_SHADOW", 'w');
+        if (cells) {
+            if (w.lc_cells < lc_cells) {
+                if (w.lc_counts) (void)hipFree(w.lc_counts);
+                if (w.lc_offsets) (void)hipFree(w.lc_offsets);
+                w.lc_counts = w.lc_offsets = nullptr;
+                w.lc_cells = 0;
+                HIP_TRY(hipMalloc((void**)&w.lc_counts, (lc_cells + 1) * 4));
+                HIP_TRY(hipMalloc((void**)&w.lc_offsets, (lc_cells + 1) * 4));
+                w.lc_cells = lc_cells;
+            }
+            const size_t want = (size_t)s->n_tris_total * 12;
+            if (w.lc_capacity < want) {
+                if (w.lc_boxes) (void)hipFree(w.lc_boxes);
+                if (w.lc_ids) (void)hipFree(w.lc_ids);
+                w.lc_boxes = nullptr;
+                w.lc_ids = nullptr;
+                w.lc_capacity = 0;
+                HIP_TRY(hipMalloc((void**)&w.lc_boxes, want * sizeof(float4)));
+                HIP_TRY(hipMalloc((void**)&w.lc_ids, want * 4));
+                w.lc_capacity = want;
+            }
+            if (!w.lc_flags) HIP_TRY(hipMalloc((void**)&w.lc_flags, 256));
+            if (!s->side_stream[set]) {
+                HIP_TRY(hipStreamCreateWithFlags(&s->side_stream[set], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&s->side_fork[set], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&s->side_done[set], hipEventDisableTiming));
+            }
+            // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
+            HIP_TRY(hipEventRecord(s->side_fork[set], ws));
+            HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
+            HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_offsets, w.lc_boxes, w.lc_ids,
+                                     (uint32_t)std::min<size_t>(w.lc_capacity, 0xFFFFFFFFu), 2048, 192, w.lc_flags,
+                                     s->side_stream[set]));
+            HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
+        }
+    }
     // Projection runs tile by tile (triangle lists per tile of 32 x 32 samples, nearest hits in LDS);
     // RAYS_HIP_RASTER=atomic keeps the older form with one nearest-hit word per sample in device memory.
     const bool raster_by_tile = raster && !env_is("RAYS_HIP_RASTER", 'a');
@@ -465,9 +525,6 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(hipStreamSynchronize(ws));
             HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
         }
-        // The library's own sort moves the keys that carry a shadow ray only and leaves their number on
-        // the device; RAYS_HIP_SORT=rocprim sorts all of them with the library sort instead.
-        const bool own_sort = !env_is("RAYS_HIP_SORT", 'r');
         if (own_sort) {
             HIP_TRY(rtk::radix_sort_valid(w.radix_work, w.keys[0], w.keys[1], w.order, n_slots, lp.key_bits, w.n_valid, ws));
         } else {
@@ -475,8 +532,14 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             HIP_TRY(rtk::sort_pairs_u32(w.temp, &tb, w.keys[0], w.keys[1], nullptr, w.order, n_slots, lp.key_bits, ws));
         }
         if (last_run) HIP_TRY(mark(2));
+        if (cells) {
+            HIP_TRY(hipStreamWaitEvent(ws, s->side_done[set], 0));
+            HIP_TRY(rtk::shadow_cells(s->view, dp, lp, (uint32_t)n_slots, w.keys[1], w.order, w.samp, w.state, d_stats,
+                                      w.n_valid, w.lc_offsets, w.lc_boxes, w.lc_ids, w.lc_flags, ws));
+        }
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
-                               w.order, w.samp, w.state, d_stats, ws, own_sort ? w.n_valid : nullptr));
+                               w.order, w.samp, w.state, d_stats, ws, own_sort ? w.n_valid : nullptr,
+                               cells ? w.lc_flags : nullptr));
         if (mode == 0) {
             if (last_run) HIP_TRY(mark(3));
             if (in_flight) {

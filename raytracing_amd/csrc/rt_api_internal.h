@@ -88,9 +88,19 @@ struct FrameWork {
     size_t temp_bytes = 0;
     void* radix_work = nullptr;      // workspace of the library's own sort (rtk::radix_sort_valid)
     uint32_t* n_valid = nullptr;     // device word: shadow rays among the sorted keys
+    // Shadow rays by light-space cells: triangles per cell (counts, then fill cursors), list offsets,
+    // the lists (a box and an id per entry), and the device words that say whether the lists are usable.
+    uint32_t* lc_counts = nullptr;
+    uint32_t* lc_offsets = nullptr;
+    size_t lc_cells = 0;
+    float4* lc_boxes = nullptr;
+    uint32_t* lc_ids = nullptr;
+    size_t lc_capacity = 0;
+    uint32_t* lc_flags = nullptr;
     void release() {
         for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp,
-                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list, (void*)bin_recs, radix_work, (void*)n_valid})
+                        (void*)bin_counts, (void*)bin_offsets, (void*)bin_list, (void*)bin_recs, radix_work, (void*)n_valid,
+                        (void*)lc_counts, (void*)lc_offsets, (void*)lc_boxes, (void*)lc_ids, (void*)lc_flags})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }
@@ -110,6 +120,10 @@ struct rt_scene {
     hipStream_t pipe_stream[2] = {nullptr, nullptr};
     hipEvent_t pipe_ready[2] = {nullptr, nullptr}, pipe_free[2] = {nullptr, nullptr};
     bool pipe_free_set[2] = {false, false};
+    // Streams on which a frame's light-space triangle lists are built beside its camera rays, one per
+    // set of buffers, with the events that order them against the frame's own stream.
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t side_fork[2] = {nullptr, nullptr}, side_done[2] = {nullptr, nullptr};
     uint64_t pipe_frames = 0;
     float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};  // over the objects that have a tree
     // Camera rays by projection (the camera of src/main.rs:314-330 stands at the origin and looks along
@@ -135,6 +149,12 @@ struct rt_scene {
                 (void)hipStreamSynchronize(pipe_stream[b]);
                 (void)hipStreamDestroy(pipe_stream[b]);
             }
+            if (side_stream[b]) {
+                (void)hipStreamSynchronize(side_stream[b]);
+                (void)hipStreamDestroy(side_stream[b]);
+            }
+            if (side_fork[b]) (void)hipEventDestroy(side_fork[b]);
+            if (side_done[b]) (void)hipEventDestroy(side_done[b]);
             if (pipe_ready[b]) (void)hipEventDestroy(pipe_ready[b]);
             if (pipe_free[b]) (void)hipEventDestroy(pipe_free[b]);
         }

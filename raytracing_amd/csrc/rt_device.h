@@ -71,7 +71,13 @@ struct DevRenderParams {
 struct LightProj {
     int w, a1, a2;                 // dominant axis of (scene centre - sun) and the two others
     float sun_w, sun_a1, sun_a2;   // sun position on those axes
+    // The projected coordinates are taken relative to the line from the sun through the scene's
+    // centre c:  u = ((p.a1 - c.a1) - uc (p.w - c.w)) / (p.w - sun.w),  uc = (c.a1 - sun.a1) / (c.w - sun.w),
+    // which is (p.a1 - sun.a1) / (p.w - sun.w) - uc with small operands: a far sun's coordinates would
+    // otherwise cost most of the float's digits.
+    float c_w, c_a1, c_a2, uc, vc;
     float u0, uscale, v0, vscale;  // quantisation of the projected coordinates to 16 bits each
+    float uabs, vabs;              // largest |u|, |v| over the scene's bounds
     uint32_t key_bits;             // leading bits of the 32-bit interleaved key that are kept (even, 8..32)
 };
 

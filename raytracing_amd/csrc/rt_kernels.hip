@@ -1945,15 +1945,25 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v) {
     return v;
 }
 
-// Light-space sort key of a shadow ray's origin: the point projected from the sun onto the plane
-// across the light's dominant axis; points on one line to the sun get (nearly) one key.
+// Light-space coordinates of a point, in the key's units (65536 across the scene's bounds), not yet
+// clamped: the point projected from the sun onto the plane across the light's dominant axis; the
+// points of one line to the sun get one pair of coordinates.
+__device__ __forceinline__ void light_uv(const LightProj& lp, rt_f3 pos, float& qu, float& qv) {
+    const float pw = pick3(pos, lp.w);
+    const float rw = 1.0f / (pw - lp.sun_w);
+    const float dw = pw - lp.c_w;
+    const float u = ((pick3(pos, lp.a1) - lp.c_a1) - lp.uc * dw) * rw;
+    const float v = ((pick3(pos, lp.a2) - lp.c_a2) - lp.vc * dw) * rw;
+    qu = (u - lp.u0) * lp.uscale;
+    qv = (v - lp.v0) * lp.vscale;
+}
+
+// Light-space sort key of a shadow ray's origin: its light-space coordinates interleaved.
 __device__ __forceinline__ uint32_t light_key(const LightProj& lp, rt_f3 pos) {
-    const float pw = pick3(pos, lp.w) - lp.sun_w;
-    const float rw = 1.0f / pw;
-    const float u = (pick3(pos, lp.a1) - lp.sun_a1) * rw;
-    const float v = (pick3(pos, lp.a2) - lp.sun_a2) * rw;
-    const float qu = fminf(fmaxf((u - lp.u0) * lp.uscale, 0.0f), 65535.0f);
-    const float qv = fminf(fmaxf((v - lp.v0) * lp.vscale, 0.0f), 65535.0f);
+    float fu, fv;
+    light_uv(lp, pos, fu, fv);
+    const float qu = fminf(fmaxf(fu, 0.0f), 65535.0f);
+    const float qv = fminf(fmaxf(fv, 0.0f), 65535.0f);
     uint32_t key = spread16((uint32_t)qu) | (spread16((uint32_t)qv) << 1);
     if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
     return key >> (32u - lp.key_bits);  // below 32 bits no key can equal the all-ones "no shadow ray" value
@@ -2987,23 +2997,343 @@ __global__ __launch_bounds__(RT_WF_BLOCK, RT_SHADOW_WAVES) void k_wf_shadow(Scen
                                                         const uint32_t* __restrict__ vals,
                                                         const float4* __restrict__ samp, uint32_t* __restrict__ state,
                                                         DevStats* __restrict__ stats,
-                                                        const uint32_t* __restrict__ n_valid) {
+                                                        const uint32_t* __restrict__ n_valid,
+                                                        const uint32_t* __restrict__ done_flag, uint32_t n_blocks) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     uint2* s_beam = reinterpret_cast<uint2*>(s_dyn) + (threadIdx.x >> 6) * p.beam_levels * 64;
-    const uint64_t i = (uint64_t)xcd_block(blockIdx.x) * RT_WF_BLOCK + threadIdx.x;
-    // n_valid (the library's own sort): the first *n_valid keys carry a shadow ray, what follows is
-    // stale. Otherwise all n keys are sorted and those without a ray, all ones, come last.
-    const bool act = n_valid ? i < *n_valid : (i < n && keys[i] != 0xFFFFFFFFu);
-    if (__ballot(act) == 0ull) return;
+    // done_flag: set when k_shadow_cells has taken this launch's rays. Such a launch is the stand-by
+    // and comes with a small grid, whose groups take the blocks of rays in turn.
+    if (done_flag && *done_flag != 0u) return;
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t i = (uint64_t)xcd_block(blk) * RT_WF_BLOCK + threadIdx.x;
+        // n_valid (the library's own sort): the first *n_valid keys carry a shadow ray, what follows is
+        // stale. Otherwise all n keys are sorted and those without a ray, all ones, come last.
+        const bool act = n_valid ? i < *n_valid : (i < n && keys[i] != 0xFFFFFFFFu);
+        if (__ballot(act) == 0ull) continue;
+        LaneStats st;
+        const uint32_t slot = act ? vals[i] : 0u;
+        const float4 a = samp[slot];
+        const rt_f3 pos = f3(a.x, a.y, a.z);
+        const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+        const rt_f3 sdir = g_normalize(sun - pos);
+        const bool occ = any_all_packet<STATS>(sv, pos, sdir, act, s_beam, st, act ? keys[i] >> cell_shift : 0u);
+        if (act && occ) state[slot] |= RT_ST_OCC;
+        if (STATS) flush_stats(st, stats);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shadow rays by light-space cells. Every shadow ray ends at the sun, so seen from the sun a ray is
+// one point (its light-space coordinates, light_uv) and a triangle a small patch: a ray can only be
+// occluded by the triangles whose patch holds its point. The sort has already grouped the rays by
+// cell of the light-space grid (the key's leading bits); here the triangles are listed per cell
+// (k_lcell_bin twice: count, then fill, k_scan_cells between them), and k_shadow_cells puts each
+// wave's 64 sorted rays against the list of their cell: a box test in light space per (ray,
+// triangle), and the pairs that pass queue up in LDS until 64 of them take the exact triangle test
+// together, one pair per lane. No tree, no stack; the exact test runs on full waves. The result is
+// the tree walk's: whether any triangle passes the reference's test does not depend on the order
+// in which they are tried.
+//
+// A triangle's patch must hold the point of every ray its exact test can accept. The test's
+// quantities are signed volumes U, V, A - U - V against thresholds of a few units of rounding of
+// M = |s| |e| (s = origin - v0, e an edge), and the distance of the ray from the edge's line, seen
+// along the ray, is U / |e x d|: a ray further outside an edge than  c u |s| |e| / |e x d|  (u = 2^-24,
+// c below 100 with everything counted, |s| at most the scene's diagonal) fails. The patch is the
+// box of the three vertices' light-space coordinates grown by that distance (512 u diag amp with
+// amp = max |e| / |e x D|, D the direction to the sun), projected (1 + |uc| + |u|) / |p.w - sun.w|
+// per unit of length, plus half a unit of the key for the rounding of the coordinates themselves. A
+// triangle with an edge within 1/256 of the direction to the sun (amp above 256; degenerate
+// triangles too) gets the patch of its eight-triangle leaf's box instead: the reference tests a
+// triangle only for rays that pass the slab test of that box (src/main.rs:103-111,
+// src/simd_accel.rs:342-377), whatever the triangle's own shape.
+// The trailing n % 8 triangles of an object take the reference's scalar test; k_shadow_cells tries
+// them on every ray first, as the tree walk does.
+// ---------------------------------------------------------------------------------------------
+#define RT_LCELL_AMP 256.0f
+#define RT_LCELL_MAX_OBJS 32u       // the objects a ray's box tests are kept for, one bit each
+#define RT_LCELL_ID_BITS 26u        // triangle ids in a list entry; the object's index above them
+
+struct LightCells {
+    uint32_t shift;       // light-space coordinate (16 bits) >> shift = cell coordinate
+    uint32_t n_cells;
+    float margin;         // 512 u x the scene's diagonal
+    float slope_u, slope_v;   // 1 + |uc| + largest |u|, and the same for v
+};
+
+__device__ __forceinline__ uint32_t lcell_of(uint32_t cx, uint32_t cy) { return spread16(cx) | (spread16(cy) << 1); }
+
+// One thread per triangle. FILL = false: counts[cell] += 1 for every cell the patch touches. FILL =
+// true: the same walk writes the patch (boxes) and the id and object (ids) at offsets[cell] + the
+// cell's cursor (counts, zero again after the scan).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams p, LightProj lp, LightCells lc,
+                                                   uint32_t n_tris_total, uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ offsets, float4* __restrict__ boxes,
+                                                   uint32_t* __restrict__ ids, uint32_t capacity,
+                                                   const uint32_t* __restrict__ flags) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    if (FILL && flags[0] == 0u) return;
+    if (id >= n_tris_total) return;
+    uint32_t moi = 0;
+    while (id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
+    const DevObject& ob = sv.objs[moi];
+    const uint32_t local = id - ob.tri_base;
+    if (local >= (ob.n_tris & ~7u)) return;   // trailing triangle
+    const float* t9 = sv.tri9 + 9 * (size_t)id;
+    const rt_f3 e1 = ld3(t9), e2 = ld3(t9 + 3), v0 = ld3(t9 + 6);
+    const rt_f3 vb = v0 + e1, vc = v0 + e2, e3 = e2 - e1;
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    const rt_f3 cen = f3((v0.x + vb.x + vc.x) * (1.0f / 3.0f), (v0.y + vb.y + vc.y) * (1.0f / 3.0f),
+                         (v0.z + vb.z + vc.z) * (1.0f / 3.0f));
+    const rt_f3 D = g_normalize(sun - cen);
+    float amp = 1.0f;
+    bool ill = false;
+    {
+        const rt_f3 es[3] = {e1, e2, e3};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const rt_f3 c = g_cross(es[k], D);
+            const float cr = __builtin_sqrtf(g_dot(c, c)), len = __builtin_sqrtf(g_dot(es[k], es[k]));
+            if (!(cr * RT_LCELL_AMP > len)) ill = true;   // NaN too
+            else amp = fmaxf(amp, len / cr);
+        }
+    }
+    float x0 = RT_INF, x1 = -RT_INF, y0 = RT_INF, y1 = -RT_INF, rwmax = 0.0f;
+    auto take = [&](rt_f3 q) {
+        float qu, qv;
+        light_uv(lp, q, qu, qv);
+        x0 = fminf(x0, qu), x1 = fmaxf(x1, qu), y0 = fminf(y0, qv), y1 = fmaxf(y1, qv);
+        rwmax = fmaxf(rwmax, __builtin_fabsf(1.0f / (pick3(q, lp.w) - lp.sun_w)));
+    };
+    if (!ill) {
+        take(v0), take(vb), take(vc);
+    } else {
+        const float* lb = sv.leaf_bounds + 6 * (size_t)(ob.leaf_base + (local >> 3));
+        const rt_f3 lo = ld3(lb), hi = ld3(lb + 3);
+        amp = 1.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) take(f3(c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z));
+    }
+    const float grow = lc.margin * amp * rwmax * 1.0001f;
+    const float padx = grow * lc.slope_u * lp.uscale + 0.5f + 1e-6f * fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1));
+    const float pady = grow * lc.slope_v * lp.vscale + 0.5f + 1e-6f * fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1));
+    x0 -= padx, x1 += padx, y0 -= pady, y1 += pady;
+    if (!(x0 <= x1) || !(y0 <= y1)) x0 = y0 = -RT_INF, x1 = y1 = RT_INF;   // NaN: every cell (and the list overflows)
+    const uint32_t cx0 = (uint32_t)fminf(fmaxf(x0, 0.0f), 65535.0f) >> lc.shift;
+    const uint32_t cx1 = (uint32_t)fminf(fmaxf(x1, 0.0f), 65535.0f) >> lc.shift;
+    const uint32_t cy0 = (uint32_t)fminf(fmaxf(y0, 0.0f), 65535.0f) >> lc.shift;
+    const uint32_t cy1 = (uint32_t)fminf(fmaxf(y1, 0.0f), 65535.0f) >> lc.shift;
+    for (uint32_t cy = cy0; cy <= cy1; ++cy)
+        for (uint32_t cx = cx0; cx <= cx1; ++cx) {
+            const uint32_t cell = lcell_of(cx, cy);
+            const uint32_t k = atomicAdd(&counts[cell], 1u);
+            if (FILL) {
+                const uint32_t pos = offsets[cell] + k;
+                if (pos < capacity) {
+                    boxes[pos] = make_float4(x0, y0, x1, y1);
+                    ids[pos] = id | (moi << RT_LCELL_ID_BITS);
+                }
+            }
+        }
+}
+
+// offsets[i] = counts[0] + ... + counts[i - 1] for i = 0 .. n; counts are set to zero. flags[0] = 1
+// when the lists fit `capacity`, no list is longer than max_len and the lists of the cells that have
+// one average at most max_mean entries: then the shadow rays go by cells, otherwise by tree walk.
+// One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_scan_cells(uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ offsets,
+                                                     uint32_t capacity, uint32_t max_len, uint32_t max_mean,
+                                                     uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_wave[16], s_max[16], s_used[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0, longest = 0, used = 0;
+    for (uint32_t first = 0; first < n; first += 4096u) {
+        const uint32_t i = first + 4u * t;
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = i + k < n ? counts[i + k] : 0u;
+            if (i + k < n) counts[i + k] = 0u;
+            longest = max(longest, c[k]);
+            used += c[k] != 0u;
+        }
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += v;
+        }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry, total = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t v = s_wave[w];
+            if (w < wave) before += v;
+            total += v;
+        }
+        uint32_t run = before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < n) offsets[i + k] = run;
+            run += c[k];
+        }
+        carry += total;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        longest = max(longest, (uint32_t)__shfl_xor(longest, off, 64));
+        used += __shfl_xor(used, off, 64);
+    }
+    if (lane == 0u) s_max[wave] = longest, s_used[wave] = used;
+    __syncthreads();
+    if (t == 0) {
+        offsets[n] = carry;
+        uint32_t m = 0, u = 0;
+        for (uint32_t w = 0; w < 16u; ++w) m = max(m, s_max[w]), u += s_used[w];
+        const bool ok = carry <= capacity && m <= max_len && (uint64_t)carry <= (uint64_t)max_mean * max(u, 1u);
+        flags[0] = ok ? 1u : 0u;
+        flags[1] = carry;
+        flags[2] = m;
+        flags[3] = u;
+    }
+}
+
+struct ShadowCellsLds {
+    float ray[6][64];       // origin and direction of the wave's rays
+    uint32_t queue[128];    // ring of (triangle entry << 6 | ray's lane) waiting for the exact test
+    uint32_t hit[2];        // rays the last batch of exact tests found occluded
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderParams p, LightProj lp,
+                                                        const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals,
+                                                        const float4* __restrict__ samp, uint32_t* __restrict__ state,
+                                                        DevStats* __restrict__ stats,
+                                                        const uint32_t* __restrict__ n_valid,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        const float4* __restrict__ boxes,
+                                                        const uint32_t* __restrict__ ids,
+                                                        const uint32_t* __restrict__ flags) {
+    __shared__ ShadowCellsLds lds;
+    if (flags[0] == 0u) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t i = (uint64_t)xcd_block(blockIdx.x) * 64u + lane;
+    const bool act = i < *n_valid;
+    unsigned long long alive = __ballot(act);
+    if (alive == 0ull) return;
     LaneStats st;
     const uint32_t slot = act ? vals[i] : 0u;
+    const uint32_t key = act ? keys[i] : 0xFFFFFFFFu;
     const float4 a = samp[slot];
-    const rt_f3 pos = f3(a.x, a.y, a.z);
+    const rt_f3 o = f3(a.x, a.y, a.z);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-    const rt_f3 sdir = g_normalize(sun - pos);
-    const bool occ = any_all_packet<STATS>(sv, pos, sdir, act, s_beam, st, act ? keys[i] >> cell_shift : 0u);
-    if (act && occ) state[slot] |= RT_ST_OCC;
-    if (STATS) flush_stats(st, stats);
+    const rt_f3 d = g_normalize(sun - o);
+    if (STATS && act) st.rays += 1;
+    float qu, qv;
+    light_uv(lp, o, qu, qv);
+    lds.ray[0][lane] = o.x, lds.ray[1][lane] = o.y, lds.ray[2][lane] = o.z;
+    lds.ray[3][lane] = d.x, lds.ray[4][lane] = d.y, lds.ray[5][lane] = d.z;
+    if (lane < 2u) lds.hit[lane] = 0u;
+    // The objects' boxes (src/main.rs:178-180), one bit per object, and their trailing triangles.
+    uint32_t objmask = 0u;
+    {
+        const rt_f3 inv = g_recip(d);
+        for (uint32_t oi = 0; oi < sv.n_objs; ++oi) {
+            const char* op = reinterpret_cast<const char*>(sv.objs) + 64 * (size_t)oi;
+            const f32x16_t ob = sload16(op);
+            const rt_f3 bbmin = f3(ob[0], ob[1], ob[2]), bbmax = f3(ob[3], ob[4], ob[5]);
+            const uint32_t rest_base = __float_as_uint(ob[10]), n_rest = __float_as_uint(ob[11]);
+            if (STATS && act) st.box += 1;
+            const bool in_obj = act && box_intersection_check(o, inv, bbmin, bbmax);
+            objmask |= in_obj ? 1u << oi : 0u;
+            for (uint32_t r = 0; r < n_rest; ++r) {
+                const char* pv = reinterpret_cast<const char*>(sv.rest_verts) + 36 * (size_t)(rest_base + r);
+                const f32x8_t va = sload8(pv);
+                const float vc2 = __uint_as_float(sload1u(pv + 32));
+                float t, u, v;
+                if (STATS && in_obj) st.tri += 1;
+                const bool h = in_obj && triangle_ray_hits(f3(va[0], va[1], va[2]), f3(va[3], va[4], va[5]),
+                                                           f3(va[6], va[7], vc2), o, d, RT_INF, &t, &u, &v);
+                alive &= ~__ballot(h);
+            }
+        }
+    }
+    const bool one_obj = sv.n_objs == 1u;
+    uint32_t head = 0, tail = 0;   // ring positions, wave-uniform
+    // The exact test for the m oldest pairs of the ring, one per lane.
+    auto flush = [&](uint32_t m) {
+        wave_lds_sync();
+        bool h = false;
+        uint32_t rl = 0;
+        if (lane < m) {
+            const uint32_t e = lds.queue[(head + lane) & 127u];
+            rl = e & 63u;
+            const float* t9 = sv.tri9 + 9 * (size_t)(e >> 6);
+            const rt_f3 e1 = ld3(t9), e2 = ld3(t9 + 3), v0 = ld3(t9 + 6);
+            const rt_f3 ro = f3(lds.ray[0][rl], lds.ray[1][rl], lds.ray[2][rl]);
+            const rt_f3 rd = f3(lds.ray[3][rl], lds.ray[4][rl], lds.ray[5][rl]);
+            const rt_tri_eval ev = tri_intersect(e1, e2, v0, ro, rd);
+            // src/main.rs:185-193: a t with a clear sign bit occludes
+            h = !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t);
+            if (STATS) st.tri += 1;
+            if (h) atomicOr(&lds.hit[rl >> 5], 1u << (rl & 31u));
+        }
+        head += m;
+        if (__ballot(h) != 0ull) {
+            wave_lds_sync();
+            const uint32_t h0 = __builtin_amdgcn_readfirstlane(lds.hit[0]), h1 = __builtin_amdgcn_readfirstlane(lds.hit[1]);
+            alive &= ~((unsigned long long)h0 | ((unsigned long long)h1 << 32));
+            wave_lds_sync();
+            if (lane < 2u) lds.hit[lane] = 0u;
+        }
+    };
+    unsigned long long todo = alive;
+    while (todo != 0ull) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(todo));
+        const unsigned long long grp = __ballot(key == c) & todo;
+        todo &= ~grp;
+        const uint32_t beg = sload1u(reinterpret_cast<const char*>(offsets + c));
+        const uint32_t end = sload1u(reinterpret_cast<const char*>(offsets + c + 1));
+        for (uint32_t j0 = beg; j0 < end; j0 += 64u) {
+            if ((alive & grp) == 0ull) break;
+            const uint32_t cnt = min(64u, end - j0);
+            float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            uint32_t ent = 0;
+            if (lane < cnt) bb = boxes[j0 + lane], ent = ids[j0 + lane];
+            if (STATS && (((alive & grp) >> lane) & 1ull)) st.box += cnt;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float x0 = bcast(bb.x, k), y0 = bcast(bb.y, k), x1 = bcast(bb.z, k), y1 = bcast(bb.w, k);
+                bool in = __builtin_amdgcn_fmed3f(qu, x0, x1) == qu && __builtin_amdgcn_fmed3f(qv, y0, y1) == qv;
+                uint32_t e = 0;
+                if (!one_obj) {
+                    e = (uint32_t)__builtin_amdgcn_readlane((int)ent, k);
+                    in = in && ((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u);
+                }
+                const unsigned long long m = __ballot(in) & alive & grp;
+                if (m == 0ull) continue;
+                if (one_obj) e = (uint32_t)__builtin_amdgcn_readlane((int)ent, k);
+                const uint32_t tid = e & ((1u << RT_LCELL_ID_BITS) - 1u);
+                if ((m >> lane) & 1ull) {
+                    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    lds.queue[(tail + before) & 127u] = (tid << 6) | lane;
+                }
+                tail += (uint32_t)__builtin_popcountll(m);
+                if (tail - head >= 64u) {
+                    flush(64u);
+                    if ((alive & grp) == 0ull) break;
+                }
+            }
+        }
+    }
+    if (tail != head) flush(tail - head);
+    if (act && !((alive >> lane) & 1ull)) state[slot] |= RT_ST_OCC;
+    if (STATS) {
+        st.bytes = 0;
+        flush_stats(st, stats);
+    }
 }
 
 template <int BLOCK>
@@ -3528,15 +3858,62 @@ hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const L
 
 hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, uint32_t cell_shift,
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                     DevStats* d_stats, hipStream_t s, const uint32_t* d_n_valid) {
+                     DevStats* d_stats, hipStream_t s, const uint32_t* d_n_valid, const uint32_t* d_done_flag) {
     if (n == 0) return hipSuccess;
     const size_t lds = (size_t)(RT_WF_BLOCK / 64) * p.beam_levels * 64 * 8;
+    const uint32_t n_blocks = xcd_grid(grid_for(n, RT_WF_BLOCK));
+    const uint32_t grid = d_done_flag ? std::min(n_blocks, 8192u) : n_blocks;
     if (d_stats)
-        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(xcd_grid(grid_for(n, RT_WF_BLOCK))), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
-                           d_vals, d_samp, d_state, d_stats, d_n_valid);
+        hipLaunchKernelGGL((k_wf_shadow<true>), dim3(grid), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
+                           d_vals, d_samp, d_state, d_stats, d_n_valid, d_done_flag, n_blocks);
     else
-        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(xcd_grid(grid_for(n, RT_WF_BLOCK))), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
-                           d_vals, d_samp, d_state, d_stats, d_n_valid);
+        hipLaunchKernelGGL((k_wf_shadow<false>), dim3(grid), dim3(RT_WF_BLOCK), lds, s, sv, p, n, cell_shift, d_keys,
+                           d_vals, d_samp, d_state, d_stats, d_n_valid, d_done_flag, n_blocks);
+    return hipGetLastError();
+}
+
+static LightCells light_cells(const SceneView& sv, const LightProj& lp) {
+    LightCells lc{};
+    lc.shift = 16u - lp.key_bits / 2u;
+    lc.n_cells = 1u << lp.key_bits;
+    // 512 u x the diagonal of the scene's bounds (at most sqrt(3) x its largest side)
+    lc.margin = 512.0f * 5.9604645e-8f * 1.7320508f * sv.scene_extent * 1.001f;
+    lc.slope_u = 1.0f + std::fabs(lp.uc) + lp.uabs;
+    lc.slope_v = 1.0f + std::fabs(lp.vc) + lp.vabs;
+    return lc;
+}
+
+hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
+                       uint32_t* d_counts, uint32_t* d_offsets, float4* d_boxes, uint32_t* d_ids, uint32_t capacity,
+                       uint32_t max_len, uint32_t max_mean, uint32_t* d_flags, hipStream_t s) {
+    if (lp.key_bits < 2 || lp.key_bits > 24 || (lp.key_bits & 1u) || sv.n_objs > RT_LCELL_MAX_OBJS ||
+        n_tris_total >= (1u << RT_LCELL_ID_BITS))
+        return hipErrorInvalidValue;
+    const LightCells lc = light_cells(sv, lp);
+    const uint32_t blocks = grid_for(n_tris_total, 256);
+    hipError_t e = hipMemsetAsync(d_counts, 0, ((size_t)lc.n_cells + 1) * 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_lcell_bin<false>), dim3(blocks), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts, d_offsets,
+                       d_boxes, d_ids, capacity, d_flags);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, d_counts, lc.n_cells, d_offsets, capacity, max_len, max_mean,
+                       d_flags);
+    hipLaunchKernelGGL((k_lcell_bin<true>), dim3(blocks), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts, d_offsets,
+                       d_boxes, d_ids, capacity, d_flags);
+    return hipGetLastError();
+}
+
+hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
+                        const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
+                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_offsets, const float4* d_boxes,
+                        const uint32_t* d_ids, const uint32_t* d_flags, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = xcd_grid(grid_for(n, 64));
+    if (d_stats)
+        hipLaunchKernelGGL((k_shadow_cells<true>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state,
+                           d_stats, d_n_valid, d_offsets, d_boxes, d_ids, d_flags);
+    else
+        hipLaunchKernelGGL((k_shadow_cells<false>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state,
+                           d_stats, d_n_valid, d_offsets, d_boxes, d_ids, d_flags);
     return hipGetLastError();
 }
 
