@@ -403,9 +403,11 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (mode == 0 && own_sort) {
         const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots);
         const size_t lc_cells = (size_t)1 << lp.key_bits;
+        // RAYS_HIP_SHADOW=walk: never; =cells: whenever the lists fit their buffers, however long they are.
+        const bool force = env_is("RAYS_HIP_SHADOW", 'c');
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 20 && s->objects.size() <= 32 &&
-                s->n_tris_total >= 32768 && s->n_tris_total < (1u << 26) &&
-                (size_t)s->n_tris_total * 4 <= lc_cells * 256 && !env_is("RAYS_HIP_SHADOW", 'w');
+                s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
+                (force || (s->n_tris_total >= 32768 && (size_t)s->n_tris_total * 4 <= lc_cells * 256));
         if (cells) {
             if (w.lc_cells < lc_cells) {
                 if (w.lc_counts) (void)hipFree(w.lc_counts);
@@ -416,7 +418,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 HIP_TRY(hipMalloc((void**)&w.lc_offsets, (lc_cells + 1) * 4));
                 w.lc_cells = lc_cells;
             }
-            const size_t want = (size_t)s->n_tris_total * 12;
+            const size_t want = std::max<size_t>((size_t)s->n_tris_total * 12, (size_t)1 << 22);
             if (w.lc_capacity < want) {
                 if (w.lc_boxes) (void)hipFree(w.lc_boxes);
                 if (w.lc_ids) (void)hipFree(w.lc_ids);
@@ -433,12 +435,16 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 HIP_TRY(hipEventCreateWithFlags(&s->side_fork[set], hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&s->side_done[set], hipEventDisableTiming));
             }
+            // Longest average list the cells are taken for (RAYS_HIP_SHADOW_CELL_MEAN overrides): the work
+            // per ray grows with it, the tree walk's does not.
+            const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
+            const uint32_t mean_limit = me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
             // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
             HIP_TRY(hipEventRecord(s->side_fork[set], ws));
             HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
             HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_offsets, w.lc_boxes, w.lc_ids,
-                                     (uint32_t)std::min<size_t>(w.lc_capacity, 0xFFFFFFFFu), 2048, 192, w.lc_flags,
-                                     s->side_stream[set]));
+                                     (uint32_t)std::min<size_t>(w.lc_capacity, 0xFFFFFFFFu), force ? 0xFFFFFFFFu : 2048u,
+                                     force ? 0xFFFFFFFFu : mean_limit, w.lc_flags, s->side_stream[set]));
             HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
         }
     }
