@@ -425,8 +425,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 w.lc_boxes = nullptr;
                 w.lc_ids = nullptr;
                 w.lc_capacity = 0;
-                HIP_TRY(hipMalloc((void**)&w.lc_boxes, want * sizeof(float4)));
-                HIP_TRY(hipMalloc((void**)&w.lc_ids, want * 4));
+                // the lists are read four entries at a time: room for a read that starts at the last one
+                HIP_TRY(hipMalloc((void**)&w.lc_boxes, (want + 4) * sizeof(float4)));
+                HIP_TRY(hipMalloc((void**)&w.lc_ids, (want + 4) * 4));
                 w.lc_capacity = want;
             }
             if (!w.lc_flags) HIP_TRY(hipMalloc((void**)&w.lc_flags, 256));

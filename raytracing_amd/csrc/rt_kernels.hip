@@ -3119,6 +3119,8 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
     const float pady = grow * lc.slope_v * lp.vscale + 0.5f + 1e-6f * fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1));
     x0 -= padx, x1 += padx, y0 -= pady, y1 += pady;
     if (!(x0 <= x1) || !(y0 <= y1)) x0 = y0 = -RT_INF, x1 = y1 = RT_INF;   // NaN: every cell (and the list overflows)
+    // widths rounded up, so that q - x0 <= width holds in float whenever q <= x1 does
+    const float bw = (x1 - x0) * 1.000001f + 1e-30f, bh = (y1 - y0) * 1.000001f + 1e-30f;
     const uint32_t cx0 = (uint32_t)fminf(fmaxf(x0, 0.0f), 65535.0f) >> lc.shift;
     const uint32_t cx1 = (uint32_t)fminf(fmaxf(x1, 0.0f), 65535.0f) >> lc.shift;
     const uint32_t cy0 = (uint32_t)fminf(fmaxf(y0, 0.0f), 65535.0f) >> lc.shift;
@@ -3130,7 +3132,7 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
             if (FILL) {
                 const uint32_t pos = offsets[cell] + k;
                 if (pos < capacity) {
-                    boxes[pos] = make_float4(x0, y0, x1, y1);
+                    boxes[pos] = make_float4(x0, bw, y0, bh);
                     ids[pos] = id | (moi << RT_LCELL_ID_BITS);
                 }
             }
@@ -3206,7 +3208,7 @@ struct ShadowCellsLds {
     uint32_t hit[2];        // rays the last batch of exact tests found occluded
 };
 
-template <bool STATS>
+template <bool STATS, bool ONE_OBJ>
 __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderParams p, LightProj lp,
                                                         const uint32_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals,
@@ -3261,16 +3263,18 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
             }
         }
     }
-    const bool one_obj = sv.n_objs == 1u;
+    // A ray that is occluded, or whose object's box it misses (one object), takes no further part:
+    // its light-space coordinate becomes NaN, which is inside no box.
+    const float nan = __uint_as_float(0x7FC00000u);
+    if (!((alive >> lane) & 1ull) || (ONE_OBJ && !(objmask & 1u))) qu = nan;
     uint32_t head = 0, tail = 0;   // ring positions, wave-uniform
     // The exact test for the m oldest pairs of the ring, one per lane.
     auto flush = [&](uint32_t m) {
         wave_lds_sync();
         bool h = false;
-        uint32_t rl = 0;
         if (lane < m) {
             const uint32_t e = lds.queue[(head + lane) & 127u];
-            rl = e & 63u;
+            const uint32_t rl = e & 63u;
             const float* t9 = sv.tri9 + 9 * (size_t)(e >> 6);
             const rt_f3 e1 = ld3(t9), e2 = ld3(t9 + 3), v0 = ld3(t9 + 6);
             const rt_f3 ro = f3(lds.ray[0][rl], lds.ray[1][rl], lds.ray[2][rl]);
@@ -3285,7 +3289,9 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         if (__ballot(h) != 0ull) {
             wave_lds_sync();
             const uint32_t h0 = __builtin_amdgcn_readfirstlane(lds.hit[0]), h1 = __builtin_amdgcn_readfirstlane(lds.hit[1]);
-            alive &= ~((unsigned long long)h0 | ((unsigned long long)h1 << 32));
+            const unsigned long long hm = (unsigned long long)h0 | ((unsigned long long)h1 << 32);
+            alive &= ~hm;
+            if ((hm >> lane) & 1ull) qu = nan;
             wave_lds_sync();
             if (lane < 2u) lds.hit[lane] = 0u;
         }
@@ -3293,38 +3299,34 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     unsigned long long todo = alive;
     while (todo != 0ull) {
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(todo));
-        const unsigned long long grp = __ballot(key == c) & todo;
+        const bool mine = key == c;
+        const unsigned long long grp = __ballot(mine);
         todo &= ~grp;
-        const uint32_t beg = sload1u(reinterpret_cast<const char*>(offsets + c));
-        const uint32_t end = sload1u(reinterpret_cast<const char*>(offsets + c + 1));
-        for (uint32_t j0 = beg; j0 < end; j0 += 64u) {
+        const uint32_t beg = sload1u(offsets + c), end = sload1u(offsets + c + 1);
+        // The lists are read four entries at a time through the scalar cache: a box is (x0, x1 - x0, y0,
+        // y1 - y0), and 0 <= q - x0 <= x1 - x0 is one unsigned comparison of the floats' bits (a negative
+        // difference has its sign bit set and compares above every positive width; so does a NaN).
+        for (uint32_t j = beg; j < end; j += 4u) {
             if ((alive & grp) == 0ull) break;
-            const uint32_t cnt = min(64u, end - j0);
-            float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            uint32_t ent = 0;
-            if (lane < cnt) bb = boxes[j0 + lane], ent = ids[j0 + lane];
-            if (STATS && (((alive & grp) >> lane) & 1ull)) st.box += cnt;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float x0 = bcast(bb.x, k), y0 = bcast(bb.y, k), x1 = bcast(bb.z, k), y1 = bcast(bb.w, k);
-                bool in = __builtin_amdgcn_fmed3f(qu, x0, x1) == qu && __builtin_amdgcn_fmed3f(qv, y0, y1) == qv;
-                uint32_t e = 0;
-                if (!one_obj) {
-                    e = (uint32_t)__builtin_amdgcn_readlane((int)ent, k);
-                    in = in && ((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u);
-                }
-                const unsigned long long m = __ballot(in) & alive & grp;
+            const f32x16_t B = sload16(boxes + j);
+            const f32x4_t E = sload4(ids + j);
+            const uint32_t cnt = min(4u, end - j);
+            if (STATS && ((alive & grp) >> lane) & 1ull) st.box += cnt;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                if (k >= cnt) break;
+                const uint32_t e = __float_as_uint(E[k]);
+                bool in = mine && __float_as_uint(qu - B[4 * k]) <= __float_as_uint(B[4 * k + 1]) &&
+                          __float_as_uint(qv - B[4 * k + 2]) <= __float_as_uint(B[4 * k + 3]);
+                if (!ONE_OBJ) in = in && ((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u);
+                const unsigned long long m = __ballot(in);
                 if (m == 0ull) continue;
-                if (one_obj) e = (uint32_t)__builtin_amdgcn_readlane((int)ent, k);
-                const uint32_t tid = e & ((1u << RT_LCELL_ID_BITS) - 1u);
-                if ((m >> lane) & 1ull) {
+                if (in) {
                     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    lds.queue[(tail + before) & 127u] = (tid << 6) | lane;
+                    lds.queue[(tail + before) & 127u] = (e << 6) | lane;   // the object's bits fall off the top
                 }
                 tail += (uint32_t)__builtin_popcountll(m);
-                if (tail - head >= 64u) {
-                    flush(64u);
-                    if ((alive & grp) == 0ull) break;
-                }
+                if (tail - head >= 64u) flush(64u);
             }
         }
     }
@@ -3908,12 +3910,17 @@ hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const Lig
                         const uint32_t* d_ids, const uint32_t* d_flags, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = xcd_grid(grid_for(n, 64));
-    if (d_stats)
-        hipLaunchKernelGGL((k_shadow_cells<true>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state,
-                           d_stats, d_n_valid, d_offsets, d_boxes, d_ids, d_flags);
-    else
-        hipLaunchKernelGGL((k_shadow_cells<false>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state,
-                           d_stats, d_n_valid, d_offsets, d_boxes, d_ids, d_flags);
+#define RT_SC_LAUNCH(ST, ONE)                                                                                          \
+    hipLaunchKernelGGL((k_shadow_cells<ST, ONE>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state, \
+                       d_stats, d_n_valid, d_offsets, d_boxes, d_ids, d_flags)
+    if (d_stats) {
+        if (sv.n_objs == 1) RT_SC_LAUNCH(true, true);
+        else RT_SC_LAUNCH(true, false);
+    } else {
+        if (sv.n_objs == 1) RT_SC_LAUNCH(false, true);
+        else RT_SC_LAUNCH(false, false);
+    }
+#undef RT_SC_LAUNCH
     return hipGetLastError();
 }
 
