@@ -400,25 +400,26 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // lists are bound to be long: about 4 n_tris / cells entries per cell. The lists depend on the
     // scene and the sun only; they are built on a stream of their own beside the camera rays.
     bool cells = false;
+    uint32_t lc_cap_shift = 8;
     if (mode == 0 && own_sort) {
         const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots);
         const size_t lc_cells = (size_t)1 << lp.key_bits;
-        // RAYS_HIP_SHADOW=walk: never; =cells: whenever the lists fit their buffers, however long they are.
+        // RAYS_HIP_SHADOW=walk: never; =cells: whenever no list outgrows its room, however long they are on average.
         const bool force = env_is("RAYS_HIP_SHADOW", 'c');
-        cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 20 && s->objects.size() <= 32 &&
+        cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
                 s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
                 (force || (s->n_tris_total >= 32768 && (size_t)s->n_tris_total * 4 <= lc_cells * 256));
+        // Room per cell: 256 entries (20 bytes each; 335 MB at 2^16 cells), 1024 when forced.
+        lc_cap_shift = force && lp.key_bits <= 16 ? 10u : 8u;
         if (cells) {
             if (w.lc_cells < lc_cells) {
                 if (w.lc_counts) (void)hipFree(w.lc_counts);
-                if (w.lc_offsets) (void)hipFree(w.lc_offsets);
-                w.lc_counts = w.lc_offsets = nullptr;
+                w.lc_counts = nullptr;
                 w.lc_cells = 0;
                 HIP_TRY(hipMalloc((void**)&w.lc_counts, (lc_cells + 1) * 4));
-                HIP_TRY(hipMalloc((void**)&w.lc_offsets, (lc_cells + 1) * 4));
                 w.lc_cells = lc_cells;
             }
-            const size_t want = std::max<size_t>((size_t)s->n_tris_total * 12, (size_t)1 << 22);
+            const size_t want = lc_cells << lc_cap_shift;
             if (w.lc_capacity < want) {
                 if (w.lc_boxes) (void)hipFree(w.lc_boxes);
                 if (w.lc_ids) (void)hipFree(w.lc_ids);
@@ -443,8 +444,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
             HIP_TRY(hipEventRecord(s->side_fork[set], ws));
             HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
-            HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_offsets, w.lc_boxes, w.lc_ids,
-                                     (uint32_t)std::min<size_t>(w.lc_capacity, 0xFFFFFFFFu), force ? 0xFFFFFFFFu : 2048u,
+            HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift,
                                      force ? 0xFFFFFFFFu : mean_limit, w.lc_flags, s->side_stream[set]));
             HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
         }
@@ -542,7 +542,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         if (cells) {
             HIP_TRY(hipStreamWaitEvent(ws, s->side_done[set], 0));
             HIP_TRY(rtk::shadow_cells(s->view, dp, lp, (uint32_t)n_slots, w.keys[1], w.order, w.samp, w.state, d_stats,
-                                      w.n_valid, w.lc_offsets, w.lc_boxes, w.lc_ids, w.lc_flags, ws));
+                                      w.n_valid, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, w.lc_flags, ws));
         }
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
                                w.order, w.samp, w.state, d_stats, ws, own_sort ? w.n_valid : nullptr,

@@ -56,20 +56,20 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
                      const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
                      DevStats* d_stats, hipStream_t s, const uint32_t* d_n_valid = nullptr,
                      const uint32_t* d_done_flag = nullptr);
-// Shadow rays by light-space cells (k_lcell_bin, k_scan_cells, k_shadow_cells). lcell_lists builds the
-// per-cell triangle lists for the grid of lp's key (2^key_bits cells; d_counts and d_offsets hold one
-// word per cell and one more) and leaves d_flags[0] = 1 when they fit `capacity` entries and are short
-// enough (max_len per list, max_mean on average over the cells that have one); d_flags[1..3] = the
-// lists' total, the longest, the cells with a list. shadow_cells then decides the first *d_n_valid
-// sorted rays when d_flags[0] is set and does nothing otherwise; wf_shadow with d_done_flag = d_flags
-// does the reverse.
+// Shadow rays by light-space cells (k_lcell_bin, k_lcell_check, k_shadow_cells). lcell_lists builds
+// the per-cell triangle lists for the grid of lp's key: 2^key_bits cells with room for 2^cap_shift entries
+// each (d_counts: one word per cell; d_boxes, d_ids: cells << cap_shift entries and four more), and leaves
+// d_flags[0] = 1 when every list fits its room and the lists of the cells that have one average at most
+// max_mean entries; d_flags[1..3] = the lists' total, the longest, the cells with a list (d_flags: 8
+// words). shadow_cells then decides the first *d_n_valid sorted rays when d_flags[0] is set and does
+// nothing otherwise; wf_shadow with d_done_flag = d_flags does the reverse.
 hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
-                       uint32_t* d_counts, uint32_t* d_offsets, float4* d_boxes, uint32_t* d_ids, uint32_t capacity,
-                       uint32_t max_len, uint32_t max_mean, uint32_t* d_flags, hipStream_t s);
+                       uint32_t* d_counts, float4* d_boxes, uint32_t* d_ids, uint32_t cap_shift, uint32_t max_mean,
+                       uint32_t* d_flags, hipStream_t s);
 hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
                         const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_offsets, const float4* d_boxes,
-                        const uint32_t* d_ids, const uint32_t* d_flags, hipStream_t s);
+                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float4* d_boxes,
+                        const uint32_t* d_ids, uint32_t cap_shift, const uint32_t* d_flags, hipStream_t s);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
 // Diffuse and mirror bounces as a pipeline: one launch of wf_bounce per level of the tree of

@@ -3062,17 +3062,14 @@ struct LightCells {
 
 __device__ __forceinline__ uint32_t lcell_of(uint32_t cx, uint32_t cy) { return spread16(cx) | (spread16(cy) << 1); }
 
-// One thread per triangle. FILL = false: counts[cell] += 1 for every cell the patch touches. FILL =
-// true: the same walk writes the patch (boxes) and the id and object (ids) at offsets[cell] + the
-// cell's cursor (counts, zero again after the scan).
-template <bool FILL>
+// One thread per triangle: for every cell its patch touches, counts[cell] += 1 and, while the cell's
+// list (room for `1 << cap_shift` entries at cell << cap_shift) has room, the patch (boxes) and the id
+// and object (ids) go into it. counts keeps counting past the room, so that k_lcell_check sees it.
 __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams p, LightProj lp, LightCells lc,
                                                    uint32_t n_tris_total, uint32_t* __restrict__ counts,
-                                                   const uint32_t* __restrict__ offsets, float4* __restrict__ boxes,
-                                                   uint32_t* __restrict__ ids, uint32_t capacity,
-                                                   const uint32_t* __restrict__ flags) {
+                                                   float4* __restrict__ boxes, uint32_t* __restrict__ ids,
+                                                   uint32_t cap_shift) {
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (FILL && flags[0] == 0u) return;
     if (id >= n_tris_total) return;
     uint32_t moi = 0;
     while (id >= sv.objs[moi].tri_base + sv.objs[moi].n_tris) ++moi;
@@ -3129,76 +3126,47 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
         for (uint32_t cx = cx0; cx <= cx1; ++cx) {
             const uint32_t cell = lcell_of(cx, cy);
             const uint32_t k = atomicAdd(&counts[cell], 1u);
-            if (FILL) {
-                const uint32_t pos = offsets[cell] + k;
-                if (pos < capacity) {
-                    boxes[pos] = make_float4(x0, bw, y0, bh);
-                    ids[pos] = id | (moi << RT_LCELL_ID_BITS);
-                }
+            if (k < (1u << cap_shift)) {
+                const size_t pos = ((size_t)cell << cap_shift) + k;
+                boxes[pos] = make_float4(x0, bw, y0, bh);
+                ids[pos] = id | (moi << RT_LCELL_ID_BITS);
             }
         }
 }
 
-// offsets[i] = counts[0] + ... + counts[i - 1] for i = 0 .. n; counts are set to zero. flags[0] = 1
-// when the lists fit `capacity`, no list is longer than max_len and the lists of the cells that have
-// one average at most max_mean entries: then the shadow rays go by cells, otherwise by tree walk.
-// One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_scan_cells(uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ offsets,
-                                                     uint32_t capacity, uint32_t max_len, uint32_t max_mean,
-                                                     uint32_t* __restrict__ flags) {
-    __shared__ uint32_t s_wave[16], s_max[16], s_used[16];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t carry = 0, longest = 0, used = 0;
-    for (uint32_t first = 0; first < n; first += 4096u) {
-        const uint32_t i = first + 4u * t;
-        uint32_t c[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c[k] = i + k < n ? counts[i + k] : 0u;
-            if (i + k < n) counts[i + k] = 0u;
-            longest = max(longest, c[k]);
-            used += c[k] != 0u;
-        }
-        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += v;
-        }
-        if (lane == 63u) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t before = carry, total = 0;
-        for (uint32_t w = 0; w < 16u; ++w) {
-            const uint32_t v = s_wave[w];
-            if (w < wave) before += v;
-            total += v;
-        }
-        uint32_t run = before + incl - mine;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i + k < n) offsets[i + k] = run;
-            run += c[k];
-        }
-        carry += total;
-        __syncthreads();
+// flags[0] = 1 when no list is longer than its room and the lists of the cells that have one average
+// at most max_mean entries: then the shadow rays go by cells, otherwise by tree walk. flags[1..3] =
+// the lists' total, the longest, the cells with a list; flags[4] counts the workgroups that are done
+// (the last one decides) and is zero again afterwards.
+__global__ __launch_bounds__(256) void k_lcell_check(const uint32_t* __restrict__ counts, uint32_t n, uint32_t cap,
+                                                     uint32_t max_mean, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_last;
+    uint32_t total = 0, longest = 0, used = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t c = counts[i];
+        total += c, longest = max(longest, c), used += c != 0u;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        total += __shfl_xor(total, off, 64);
         longest = max(longest, (uint32_t)__shfl_xor(longest, off, 64));
         used += __shfl_xor(used, off, 64);
     }
-    if (lane == 0u) s_max[wave] = longest, s_used[wave] = used;
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&flags[1], total);
+        atomicMax(&flags[2], longest);
+        atomicAdd(&flags[3], used);
+    }
+    __threadfence();
     __syncthreads();
-    if (t == 0) {
-        offsets[n] = carry;
-        uint32_t m = 0, u = 0;
-        for (uint32_t w = 0; w < 16u; ++w) m = max(m, s_max[w]), u += s_used[w];
-        const bool ok = carry <= capacity && m <= max_len && (uint64_t)carry <= (uint64_t)max_mean * max(u, 1u);
+    if (threadIdx.x == 0) s_last = atomicAdd(&flags[4], 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t t = atomicAdd(&flags[1], 0u), m = atomicAdd(&flags[2], 0u), u = atomicAdd(&flags[3], 0u);
+        const bool ok = m <= cap && (uint64_t)t <= (uint64_t)max_mean * max(u, 1u);
         flags[0] = ok ? 1u : 0u;
-        flags[1] = carry;
-        flags[2] = m;
-        flags[3] = u;
+        flags[4] = 0u;
     }
 }
 
@@ -3215,9 +3183,9 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
                                                         const float4* __restrict__ samp, uint32_t* __restrict__ state,
                                                         DevStats* __restrict__ stats,
                                                         const uint32_t* __restrict__ n_valid,
-                                                        const uint32_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ counts,
                                                         const float4* __restrict__ boxes,
-                                                        const uint32_t* __restrict__ ids,
+                                                        const uint32_t* __restrict__ ids, uint32_t cap_shift,
                                                         const uint32_t* __restrict__ flags) {
     __shared__ ShadowCellsLds lds;
     if (flags[0] == 0u) return;
@@ -3302,7 +3270,7 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         const bool mine = key == c;
         const unsigned long long grp = __ballot(mine);
         todo &= ~grp;
-        const uint32_t beg = sload1u(offsets + c), end = sload1u(offsets + c + 1);
+        const uint32_t beg = c << cap_shift, end = beg + sload1u(counts + c);
         // The lists are read four entries at a time through the scalar cache: a box is (x0, x1 - x0, y0,
         // y1 - y0), and 0 <= q - x0 <= x1 - x0 is one unsigned comparison of the floats' bits (a negative
         // difference has its sign bit set and compares above every positive width; so does a NaN).
@@ -3886,33 +3854,32 @@ static LightCells light_cells(const SceneView& sv, const LightProj& lp) {
 }
 
 hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
-                       uint32_t* d_counts, uint32_t* d_offsets, float4* d_boxes, uint32_t* d_ids, uint32_t capacity,
-                       uint32_t max_len, uint32_t max_mean, uint32_t* d_flags, hipStream_t s) {
+                       uint32_t* d_counts, float4* d_boxes, uint32_t* d_ids, uint32_t cap_shift, uint32_t max_mean,
+                       uint32_t* d_flags, hipStream_t s) {
     if (lp.key_bits < 2 || lp.key_bits > 24 || (lp.key_bits & 1u) || sv.n_objs > RT_LCELL_MAX_OBJS ||
-        n_tris_total >= (1u << RT_LCELL_ID_BITS))
+        n_tris_total >= (1u << RT_LCELL_ID_BITS) || lp.key_bits + cap_shift > 31u)
         return hipErrorInvalidValue;
     const LightCells lc = light_cells(sv, lp);
-    const uint32_t blocks = grid_for(n_tris_total, 256);
-    hipError_t e = hipMemsetAsync(d_counts, 0, ((size_t)lc.n_cells + 1) * 4, s);
+    hipError_t e = hipMemsetAsync(d_counts, 0, (size_t)lc.n_cells * 4, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_lcell_bin<false>), dim3(blocks), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts, d_offsets,
-                       d_boxes, d_ids, capacity, d_flags);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, d_counts, lc.n_cells, d_offsets, capacity, max_len, max_mean,
-                       d_flags);
-    hipLaunchKernelGGL((k_lcell_bin<true>), dim3(blocks), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts, d_offsets,
-                       d_boxes, d_ids, capacity, d_flags);
+    e = hipMemsetAsync(d_flags, 0, 32, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lcell_bin, dim3(grid_for(n_tris_total, 256)), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts,
+                       d_boxes, d_ids, cap_shift);
+    hipLaunchKernelGGL(k_lcell_check, dim3(std::min(64u, grid_for(lc.n_cells, 256))), dim3(256), 0, s, d_counts, lc.n_cells,
+                       1u << cap_shift, max_mean, d_flags);
     return hipGetLastError();
 }
 
 hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
                         const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_offsets, const float4* d_boxes,
-                        const uint32_t* d_ids, const uint32_t* d_flags, hipStream_t s) {
+                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float4* d_boxes,
+                        const uint32_t* d_ids, uint32_t cap_shift, const uint32_t* d_flags, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = xcd_grid(grid_for(n, 64));
 #define RT_SC_LAUNCH(ST, ONE)                                                                                          \
     hipLaunchKernelGGL((k_shadow_cells<ST, ONE>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state, \
-                       d_stats, d_n_valid, d_offsets, d_boxes, d_ids, d_flags)
+                       d_stats, d_n_valid, d_counts, d_boxes, d_ids, cap_shift, d_flags)
     if (d_stats) {
         if (sv.n_objs == 1) RT_SC_LAUNCH(true, true);
         else RT_SC_LAUNCH(true, false);
