@@ -3264,38 +3264,59 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
             if (lane < 2u) lds.hit[lane] = 0u;
         }
     };
+    // One list entry against the rays of the current cell (quc: their coordinate, NaN for the others).
+    float quc = nan;
+    auto entry = [&](float x0, float bw, float y0, float bh, uint32_t e) {
+        // 0 <= q - x0 <= x1 - x0 as one unsigned comparison of the floats' bits: a negative difference
+        // has its sign bit set and compares above every positive width; so does a NaN.
+        bool in = (__float_as_uint(quc - x0) <= __float_as_uint(bw)) & (__float_as_uint(qv - y0) <= __float_as_uint(bh));
+        if (!ONE_OBJ) in = in & (((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u) != 0u);
+        const unsigned long long m = __ballot(in);
+        if (m == 0ull) return;
+        if (in) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            lds.queue[(tail + before) & 127u] = (e << 6) | lane;   // the object's bits fall off the top
+        }
+        tail += (uint32_t)__builtin_popcountll(m);
+        if (tail - head >= 64u) {
+            flush(64u);
+            if (qu != qu) quc = nan;
+        }
+    };
+    auto four = [&](const f32x16_t& B, const f32x4_t& E, uint32_t cnt) {
+        if (STATS && quc == quc) st.box += cnt;
+        entry(B[0], B[1], B[2], B[3], __float_as_uint(E[0]));
+        if (cnt > 1u) entry(B[4], B[5], B[6], B[7], __float_as_uint(E[1]));
+        if (cnt > 2u) entry(B[8], B[9], B[10], B[11], __float_as_uint(E[2]));
+        if (cnt > 3u) entry(B[12], B[13], B[14], B[15], __float_as_uint(E[3]));
+    };
     unsigned long long todo = alive;
     while (todo != 0ull) {
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(todo));
         const bool mine = key == c;
         const unsigned long long grp = __ballot(mine);
         todo &= ~grp;
+        quc = mine ? qu : nan;
         const uint32_t beg = c << cap_shift, end = beg + sload1u(counts + c);
-        // The lists are read four entries at a time through the scalar cache: a box is (x0, x1 - x0, y0,
-        // y1 - y0), and 0 <= q - x0 <= x1 - x0 is one unsigned comparison of the floats' bits (a negative
-        // difference has its sign bit set and compares above every positive width; so does a NaN).
-        for (uint32_t j = beg; j < end; j += 4u) {
+        // The lists are read four entries at a time through the scalar cache (a box is x0, x1 - x0, y0,
+        // y1 - y0), the next four while the present four are worked on: the address of the next read
+        // is made to depend on the present data (a width's sign bit, always clear), which keeps the
+        // compiler from issuing it ahead of the wait for that data and then waiting for both.
+        if (beg == end) continue;
+        f32x16_t B0 = sload16(boxes + beg), B1 = B0;
+        f32x4_t E0 = sload4(ids + beg), E1 = E0;
+        for (uint32_t j = beg;;) {
             if ((alive & grp) == 0ull) break;
-            const f32x16_t B = sload16(boxes + j);
-            const f32x4_t E = sload4(ids + j);
-            const uint32_t cnt = min(4u, end - j);
-            if (STATS && ((alive & grp) >> lane) & 1ull) st.box += cnt;
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                if (k >= cnt) break;
-                const uint32_t e = __float_as_uint(E[k]);
-                bool in = mine && __float_as_uint(qu - B[4 * k]) <= __float_as_uint(B[4 * k + 1]) &&
-                          __float_as_uint(qv - B[4 * k + 2]) <= __float_as_uint(B[4 * k + 3]);
-                if (!ONE_OBJ) in = in && ((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u);
-                const unsigned long long m = __ballot(in);
-                if (m == 0ull) continue;
-                if (in) {
-                    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    lds.queue[(tail + before) & 127u] = (e << 6) | lane;   // the object's bits fall off the top
-                }
-                tail += (uint32_t)__builtin_popcountll(m);
-                if (tail - head >= 64u) flush(64u);
-            }
+            uint32_t nx = j + 4u + (__float_as_uint(B0[1]) >> 31);
+            if (nx < end) B1 = sload16(boxes + nx), E1 = sload4(ids + nx);
+            four(B0, E0, min(4u, end - j));
+            j = nx;
+            if (j >= end || (alive & grp) == 0ull) break;
+            nx = j + 4u + (__float_as_uint(B1[1]) >> 31);
+            if (nx < end) B0 = sload16(boxes + nx), E0 = sload4(ids + nx);
+            four(B1, E1, min(4u, end - j));
+            j = nx;
+            if (j >= end) break;
         }
     }
     if (tail != head) flush(tail - head);

@@ -9,7 +9,7 @@ acc = collections.OrderedDict()
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if "k_wf" not in k and "k_render" not in k and "k_trace" not in k and "rocprim" not in k and "k_raster" not in k:
+        if not any(t in k for t in ("k_wf", "k_render", "k_trace", "rocprim", "k_raster", "k_shadow", "k_lcell", "k_radix")):
             continue
         if "rocprim" in k:
             k = "rocprim radix sort (all passes)"
