@@ -400,7 +400,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // lists are bound to be long: about 4 n_tris / cells entries per cell. The lists depend on the
     // scene and the sun only; they are built on a stream of their own beside the camera rays.
     bool cells = false;
-    uint32_t lc_cap_shift = 8;
+    uint32_t lc_cap_shift = 8, lc_mean = 0;
     if (mode == 0 && own_sort) {
         const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots);
         const size_t lc_cells = (size_t)1 << lp.key_bits;
@@ -441,14 +441,21 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             // per ray grows with it, the tree walk's does not.
             const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
             const uint32_t mean_limit = me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
-            // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
-            HIP_TRY(hipEventRecord(s->side_fork[set], ws));
-            HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
-            HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift,
-                                     force ? 0xFFFFFFFFu : mean_limit, w.lc_flags, s->side_stream[set]));
-            HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
+            lc_mean = force ? 0xFFFFFFFFu : mean_limit;
         }
     }
+    // Starts the list building on the side stream, after what `ws` holds so far (the scene and the sun
+    // are all the lists depend on).
+    auto start_lists = [&]() -> int {
+        const LightProj lp = light_projection(s, p, (size_t)total_tiles * tile_slots);
+        // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
+        HIP_TRY(hipEventRecord(s->side_fork[set], ws));
+        HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
+        HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, lc_mean,
+                                 w.lc_flags, s->side_stream[set]));
+        HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
+        return RT_OK;
+    };
     // Projection runs tile by tile (triangle lists per tile of 32 x 32 samples, nearest hits in LDS);
     // RAYS_HIP_RASTER=atomic keeps the older form with one nearest-hit word per sample in device memory.
     const bool raster_by_tile = raster && !env_is("RAYS_HIP_RASTER", 'a');
@@ -512,6 +519,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const bool clear = !w.zbuf_clean;
         w.zbuf_clean = false;  // until the record pass has been through every tile of this frame
         HIP_TRY(rtk::raster_depth(s->view, dp, n_packed, w.cam_table, w.zbuf, clear, d_stats, ws));
+    }
+    // Beside the camera rays' main kernel, which is bound by arithmetic, not beside their binning, which
+    // like the list building is bound by atomics (measured: 0.07 ms dearer camera rays here, 0.15 ms there).
+    if (cells) {
+        rc = start_lists();
+        if (rc != RT_OK) return rc;
     }
     for (uint32_t first = 0; first < total_tiles; first += run_tiles) {
         const bool last_run = first + run_tiles >= total_tiles;
