@@ -334,6 +334,7 @@ def main():
     tree_walk = None
     if world == 1 and not args.no_extras:
         os.environ["RAYS_HIP_RASTER"] = "0"
+        os.environ["RAYS_HIP_SHADOW"] = "walk"
         st_walk = scene.render_device_stats(p, frames[0].data_ptr())
         walk_events = [[new_event() for _ in range(7)] for _ in range(args.steps)]
         for i in range(args.warmup):
@@ -345,6 +346,7 @@ def main():
         fence()
         dt_walk = time.perf_counter() - t0
         del os.environ["RAYS_HIP_RASTER"]
+        del os.environ["RAYS_HIP_SHADOW"]
         walk_ms = [float(np.mean([elapsed_ms(ev[k], ev[k + 1]) for ev in walk_events])) for k in range(4)]
         tree_walk = {
             "value": st_walk["rays"] * args.steps / dt_walk / 1e6,
@@ -379,7 +381,22 @@ def main():
         n_samples_rank = st["primary_rays"]
         n_shadow_rank = st["rays"] - st["primary_rays"]
         projected = bool(st["camera_by_projection"])
-        if projected or phase_ms[2] > phase_ms[0]:
+        by_cells = bool(st["shadow_by_cells"])
+        alg_parts = None
+        if by_cells:
+            # k_shadow_cells, the frame's longest kernel: per shadow ray its sorted key (4 B), slot number
+            # (4 B), hit point (16 B) and state word read and written back (8 B); every list entry once
+            # (box 16 B + id 4 B), a count per cell (4 B), the triangles' data once (36 B each).
+            kernel, kernel_ms = "k_shadow_cells", phase_ms[2]
+            alg_parts = {"per_ray": 32 * n_shadow_rank, "list_entries": 20 * st["shadow_list_entries"],
+                         "cell_counts": 4 * st["shadow_list_cells"], "triangles": 36 * args.tris}
+            alg_bytes = sum(alg_parts.values())
+            # what the loads ask the caches for: every wave reads its cells' lists (16 B per box test of a
+            # wave; the instrumented build counts box tests per unoccluded ray, so this is a lower bound)
+            # and 36 B of triangle data per pair tested
+            my_box, my_tri = st["box_tests"] - st["primary_box_tests"], st["tri_tests"] - st["primary_tri_tests"]
+            requested_bytes = alg_parts["per_ray"] + 36 * my_tri + 20 * my_box // 64
+        elif projected or phase_ms[2] > phase_ms[0]:
             # k_wf_shadow: the sorted key of every sample slot in (4 B; slots without a shadow ray end
             # there), per shadow ray its slot number (4 B), hit point (16 B) and state word read and
             # written back (8 B), the wide tree and the triangle records once.
@@ -396,15 +413,16 @@ def main():
             alg_bytes = 24 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
             requested_bytes = 24 * n_samples_rank + st["primary_fetch_bytes"]
             my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
-        alg_flops = FLOP_BOX * my_box + FLOP_TRI * my_tri
+        # a light-space box test is 2 subtractions and 2 comparisons
+        alg_flops = (4 if by_cells else FLOP_BOX) * my_box + FLOP_TRI * my_tri
         achieved = alg_bytes / (kernel_ms * 1e-3)
         # HBM traffic needs hardware counters (rocprofv3 --pmc passes of this very command): not
         # measured inside this process. The kept summaries are under profiles/.
         traffic = None
         out = {
             "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays; camera rays' nearest hits by "
-                      "projection of the triangles onto the sample grid, shadow rays by tree walk; "
-                      "value_tree_walk = every ray by tree walk)",
+                      "projection of the triangles onto the sample grid, shadow rays against per-cell triangle "
+                      "lists of a light-space grid; value_tree_walk = every ray by tree walk)",
             "value": value,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -425,6 +443,9 @@ def main():
                 "phase_ms": {"camera_rays": phase_ms[0], "shadow_sort": phase_ms[1], "shadow_rays": phase_ms[2],
                              "resolve": phase_ms[3]},
                 "camera_rays_by": "projection of the triangles onto the sample grid" if projected else "beam walk",
+                "shadow_rays_by": "light-space cells" if by_cells else "beam walk",
+                "shadow_lists": {"entries": st["shadow_list_entries"], "longest": st["shadow_list_longest"],
+                                 "cells_with_a_list": st["shadow_list_cells"]},
                 "camera_phase_counters": {"triangle_tests": st["primary_tri_tests"], "object_box_tests": st["primary_box_tests"],
                                           "node_visits_or_sample_blocks": st["primary_node_visits"]},
                 "scene_build_s": build_s,
@@ -447,6 +468,7 @@ def main():
                 "traffic_profile": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)",
                 "kernel_ms": kernel_ms,
                 "alg_bytes_per_launch": alg_bytes,
+                "alg_bytes_parts": alg_parts,
                 "requested_bytes_per_launch": requested_bytes,
                 "requested_tb_per_s": requested_bytes / (kernel_ms * 1e-3) / 1e12,
                 "valu_tflops": alg_flops / (kernel_ms * 1e-3) / 1e12,

@@ -99,6 +99,12 @@ typedef struct {
     /* The launches that trace the secondary rays of a frame with diffuse scattering (scatter and
      * mirror rays, every level; their shadow rays are not among them): zero for other frames.   */
     uint64_t bounce_rays, bounce_box_tests, bounce_tri_tests, bounce_node_visits, bounce_fetch_bytes;
+    /* Shadow rays of a camera + shadow frame by light-space cells (1) or by tree walk (0). By cells,
+     * box_tests counts the light-space box tests of rays still unoccluded, tri_tests the pairs put
+     * through the triangle test, and the shadow rays add nothing to node_visits and fetch_bytes.
+     * shadow_list_*: the per-cell triangle lists of the frame (all entries, the longest list, the
+     * cells that have one); zero when the lists were not built.                                  */
+    uint64_t shadow_by_cells, shadow_list_entries, shadow_list_longest, shadow_list_cells;
 } rt_stats;
 
 /* Number of events rt_render_device_events records. */

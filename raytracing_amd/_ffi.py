@@ -71,6 +71,10 @@ class rt_stats(C.Structure):
         ("bounce_tri_tests", C.c_uint64),
         ("bounce_node_visits", C.c_uint64),
         ("bounce_fetch_bytes", C.c_uint64),
+        ("shadow_by_cells", C.c_uint64),
+        ("shadow_list_entries", C.c_uint64),
+        ("shadow_list_longest", C.c_uint64),
+        ("shadow_list_cells", C.c_uint64),
     ]
 
 

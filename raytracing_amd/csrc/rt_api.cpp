@@ -254,7 +254,7 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
 // primary_stats: null, or receives the counters as they stand after the camera-ray kernel.
 int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, DevStats* d_stats,
                   hipStream_t stream, void* const* events = nullptr, DevStats* primary_stats = nullptr,
-                  bool* projected = nullptr, DevStats* bounce_stats = nullptr) {
+                  bool* projected = nullptr, DevStats* bounce_stats = nullptr, bool* lists_built = nullptr) {
     hipStream_t ws = stream;   // where the phases before the resolve kernel run (see in_flight below)
     auto mark = [&](int k) -> hipError_t {
         return events ? hipEventRecord((hipEvent_t)events[k], k <= 3 ? ws : stream) : hipSuccess;
@@ -522,6 +522,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     }
     // Beside the camera rays' main kernel, which is bound by arithmetic, not beside their binning, which
     // like the list building is bound by atomics (measured: 0.07 ms dearer camera rays here, 0.15 ms there).
+    if (lists_built) *lists_built = cells;
     if (cells) {
         rc = start_lists();
         if (rc != RT_OK) return rc;
@@ -1226,9 +1227,16 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     HIP_TRY(hipMemset(d_stats, 0, sizeof(DevStats)));
     DevStats hp{}, hb{};
     bool projected = false;
-    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp, &projected, &hb);
+    bool lists = false;
+    int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp, &projected, &hb, &lists);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    uint32_t lf[4] = {0, 0, 0, 0};   // usable, entries, longest, cells with a list (k_lcell_check)
+    if (lists) HIP_TRY(hipMemcpy(lf, s->work.lc_flags, sizeof(lf), hipMemcpyDeviceToHost));
+    stats->shadow_by_cells = lf[0];
+    stats->shadow_list_entries = lf[1];
+    stats->shadow_list_longest = lf[2];
+    stats->shadow_list_cells = lf[3];
     DevStats h;
     HIP_TRY(hipMemcpy(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
     stats->rays = h.rays;

@@ -84,6 +84,10 @@ pub struct rt_stats {
     pub bounce_tri_tests: u64,
     pub bounce_node_visits: u64,
     pub bounce_fetch_bytes: u64,
+    pub shadow_by_cells: u64,
+    pub shadow_list_entries: u64,
+    pub shadow_list_longest: u64,
+    pub shadow_list_cells: u64,
 }
 
 extern "C" {

@@ -13,8 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _took_cells(stats):
-    """The cells path walks no tree: every node visit of the frame is then a camera ray's."""
-    return stats["node_visits"] == stats["primary_node_visits"]
+    """The library's own word, and what it implies: the cells walk no tree, so every node visit of
+    the frame is then a camera ray's."""
+    if stats["shadow_by_cells"]:
+        assert stats["node_visits"] == stats["primary_node_visits"]
+        assert stats["shadow_list_entries"] >= stats["shadow_list_longest"] > 0 and stats["shadow_list_cells"] > 0
+    return bool(stats["shadow_by_cells"])
 
 
 def _render_stats(g, p):
