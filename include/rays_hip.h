@@ -191,7 +191,9 @@ int  rt_render(rt_scene*, const rt_render_params*, uint8_t* rgba8, uint32_t* hit
  * workspace, so that consecutive frames overlap on the GPU; they are ordered behind nothing on
  * `stream` (they read the immutable scene and the parameters, which are copied at the call) and the
  * last kernel waits for them. RAYS_HIP_FRAMES_IN_FLIGHT=1 in the environment keeps every phase on
- * `stream` (needed under stream capture). */
+ * `stream` (needed under stream capture), except that the triangle lists of the light-space shadow
+ * search (scenes of 32,768 triangles or more) are built on a stream of the scene's own that is forked
+ * from `stream` and joined to it again by events inside the call. */
 int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                       void* stream);
 /* As rt_render_device, and records the caller's hipEvent_t handles on the stream around the
