@@ -3027,7 +3027,7 @@ __global__ __launch_bounds__(RT_WF_BLOCK, RT_SHADOW_WAVES) void k_wf_shadow(Scen
 // one point (its light-space coordinates, light_uv) and a triangle a small patch: a ray can only be
 // occluded by the triangles whose patch holds its point. The sort has already grouped the rays by
 // cell of the light-space grid (the key's leading bits); here the triangles are listed per cell
-// (k_lcell_bin twice: count, then fill, k_scan_cells between them), and k_shadow_cells puts each
+// (k_lcell_bin; k_lcell_check says whether the lists came out usable), and k_shadow_cells puts each
 // wave's 64 sorted rays against the list of their cell: a box test in light space per (ray,
 // triangle), and the pairs that pass queue up in LDS until 64 of them take the exact triangle test
 // together, one pair per lane. No tree, no stack; the exact test runs on full waves. The result is
