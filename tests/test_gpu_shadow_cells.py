@@ -170,3 +170,44 @@ def test_cells_with_triangles_edge_on_to_the_light(ctx, oracle, monkeypatch, kin
                               _edge_on_to(rng, sun, 8, 2.0)])
     objs = [_as_object(np.concatenate([occ, rv, big]).astype(np.float32))]
     _frames(ctx, oracle, objs, monkeypatch, [(160, 90, 2), (128, 72, 4)], sun=sun)
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_cells_in_sharded_frames(soup200k, monkeypatch, shards):
+    """A shard's rays are a fraction of the frame's, spread over all the light-space cells; the lists
+    are the whole scene's on every shard. The shards' tiles must add up to the frame rendered whole,
+    and to the frame the tree walk gives."""
+    objs, g = soup200k
+    W, H = 1000, 600     # not a multiple of the tile size
+    kw = dict(reflect_depth=1, diffuse_depth=1, sun=SUNS["reference_quarter_turn"])
+    full, st = _render_stats(g, render_params(W, H, 2, **kw))
+    assert _took_cells(st)
+    acc = np.zeros_like(full)
+    for r in range(shards):
+        part = g.render(render_params(W, H, 2, shard_index=r, shard_count=shards, **kw))
+        assert not (acc.astype(bool) & part.astype(bool))[..., 3].any(), "two shards wrote one pixel"
+        acc |= part
+    assert np.array_equal(acc, full)
+    monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+    assert np.array_equal(g.render(render_params(W, H, 2, **kw)), full)
+
+
+def test_cells_follow_a_moving_sun_frame_by_frame(soup200k, monkeypatch):
+    """The lists are rebuilt for every frame's sun: frames enqueued back to back (two in flight inside
+    the library) under a sun that moves must equal the tree walk's frames of the same suns."""
+    import torch
+    objs, g = soup200k
+    W, H = 640, 360
+    params = [render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.sun_at(3.3 * k)) for k in range(5)]
+    monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+    ref = [g.render(p) for p in params]
+    monkeypatch.delenv("RAYS_HIP_SHADOW")
+    monkeypatch.setenv("RAYS_HIP_FRAMES_IN_FLIGHT", "2")
+    bufs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in params]
+    torch.cuda.synchronize()
+    for p, buf in zip(params, bufs):
+        g.render_device(p, buf.data_ptr())
+    torch.cuda.synchronize()
+    for k, buf in enumerate(bufs):
+        assert np.array_equal(buf.cpu().numpy(), ref[k]), f"frame {k}"
+    assert any(not np.array_equal(ref[0], r) for r in ref[1:])
