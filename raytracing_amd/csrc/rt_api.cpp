@@ -409,7 +409,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
                 s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
                 (force || (s->n_tris_total >= 32768 && (size_t)s->n_tris_total * 4 <= lc_cells * 256));
-        // Room per cell: 256 entries (20 bytes each; 335 MB at 2^16 cells), 1024 when forced.
+        // Room per cell: 256 entries (24 bytes each; 403 MB at 2^16 cells), 1024 when forced.
         lc_cap_shift = force && lp.key_bits <= 16 ? 10u : 8u;
         if (cells) {
             if (w.lc_cells < lc_cells) {
@@ -428,7 +428,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 w.lc_capacity = 0;
                 // the lists are read four entries at a time: room for a read that starts at the last one
                 HIP_TRY(hipMalloc((void**)&w.lc_boxes, (want + 4) * sizeof(float4)));
-                HIP_TRY(hipMalloc((void**)&w.lc_ids, (want + 4) * 4));
+                HIP_TRY(hipMalloc((void**)&w.lc_ids, (want + 4) * 8));   // id and depth
                 w.lc_capacity = want;
             }
             if (!w.lc_flags) HIP_TRY(hipMalloc((void**)&w.lc_flags, 256));

@@ -3048,6 +3048,21 @@ __global__ __launch_bounds__(RT_WF_BLOCK, RT_SHADOW_WAVES) void k_wf_shadow(Scen
 // src/simd_accel.rs:342-377), whatever the triangle's own shape.
 // The trailing n % 8 triangles of an object take the reference's scalar test; k_shadow_cells tries
 // them on every ray first, as the tree walk does.
+//
+// Depth. A triangle occludes a ray only from between the ray's origin and the sun, so an entry also
+// carries the least depth of its vertices (depth = distance from the scene's centre along the light's
+// dominant axis, growing away from the sun), lowered by a bound on what rounding can accept, and a
+// ray nearer the sun than that skips the entry. The bound: the test's point X = o + t d = v0 + u e1 +
+// v e2 (exact arithmetic) has depth (1-u-v) z0 + u z1 + v z2 and, for t >= 0, a depth no larger than
+// the origin's. Rounding moves each of the test's signed volumes by less than 32 u |s| |e| (u =
+// 2^-24), so an accepted ray has exact u, v, 1-u-v >= -eta and t >= -eta max|e| with eta = 32 u diag
+// max|e| / |a|, and |a| = |N . d| = G / |S - X| with N = e1 x e2, G = |(S - v0) . N|, S the sun. With
+// kappa = 512 u diag max|e| R / G and R = 2 (max |S - Pi| + 2 max|e|), kappa <= 1/4 keeps the computed
+// sign of a right and X within R of the sun (a point further out is so far outside the triangle that
+// one of the volumes is wrong by G / (8 max|e|), more than rounding gives), hence eta <= kappa / 16:
+// the entry's depth is  min z - kappa (|z1-z0| + |z2-z0| + |z2-z1| + max|e|).  Triangles with kappa
+// above 1/4 (nearly edge-on to the sun), and those that took their leaf's patch, get no depth: every
+// ray of the patch tests them.
 // ---------------------------------------------------------------------------------------------
 #define RT_LCELL_AMP 256.0f
 #define RT_LCELL_MAX_OBJS 32u       // the objects a ray's box tests are kept for, one bit each
@@ -3058,13 +3073,16 @@ struct LightCells {
     uint32_t n_cells;
     float margin;         // 512 u x the scene's diagonal
     float slope_u, slope_v;   // 1 + |uc| + largest |u|, and the same for v
+    float away;           // +1 when the light's dominant coordinate grows away from the sun, -1 otherwise
+    float depth_span;     // the scene's extent along that axis
 };
 
 __device__ __forceinline__ uint32_t lcell_of(uint32_t cx, uint32_t cy) { return spread16(cx) | (spread16(cy) << 1); }
 
 // One thread per triangle: for every cell its patch touches, counts[cell] += 1 and, while the cell's
 // list (room for `1 << cap_shift` entries at cell << cap_shift) has room, the patch (boxes) and the id
-// and object (ids) go into it. counts keeps counting past the room, so that k_lcell_check sees it.
+// and object with the entry's depth (ids, two words an entry) go into it. counts keeps counting past
+// the room, so that k_lcell_check sees it.
 __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams p, LightProj lp, LightCells lc,
                                                    uint32_t n_tris_total, uint32_t* __restrict__ counts,
                                                    float4* __restrict__ boxes, uint32_t* __restrict__ ids,
@@ -3111,6 +3129,24 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
 #pragma unroll
         for (int c = 0; c < 8; ++c) take(f3(c & 1 ? hi.x : lo.x, c & 2 ? hi.y : lo.y, c & 4 ? hi.z : lo.z));
     }
+    // Least depth a ray must have for this triangle to lie between it and the sun (see above).
+    float zcull = -RT_INF;
+    if (!ill) {
+        const float z0 = (pick3(v0, lp.w) - lp.c_w) * lc.away, z1 = (pick3(vb, lp.w) - lp.c_w) * lc.away,
+                    z2 = (pick3(vc, lp.w) - lp.c_w) * lc.away;
+        const rt_f3 N = g_cross(e1, e2);
+        const rt_f3 s0 = sun - v0, s1 = sun - vb, s2 = sun - vc;
+        const float G = __builtin_fabsf(g_dot(s0, N));
+        const float r0 = __builtin_sqrtf(fmaxf(g_dot(s0, s0), fmaxf(g_dot(s1, s1), g_dot(s2, s2))));
+        const float emax = __builtin_sqrtf(fmaxf(g_dot(e1, e1), fmaxf(g_dot(e2, e2), g_dot(e3, e3))));
+        const float kappa = lc.margin * emax * (2.0f * (r0 + 2.0f * emax)) / G * 1.001f;
+        if (kappa <= 0.25f) {   // false for NaN
+            const float zmin = fminf(z0, fminf(z1, z2)), zabs = fmaxf(__builtin_fabsf(z0), fmaxf(__builtin_fabsf(z1), __builtin_fabsf(z2)));
+            const float spread = __builtin_fabsf(z1 - z0) + __builtin_fabsf(z2 - z0) + __builtin_fabsf(z2 - z1) + emax;
+            zcull = zmin - kappa * spread * 1.001f - 4e-6f * (zabs + lc.depth_span);
+            if (!(zcull == zcull)) zcull = -RT_INF;
+        }
+    }
     const float grow = lc.margin * amp * rwmax * 1.0001f;
     const float padx = grow * lc.slope_u * lp.uscale + 0.5f + 1e-6f * fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1));
     const float pady = grow * lc.slope_v * lp.vscale + 0.5f + 1e-6f * fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1));
@@ -3129,7 +3165,7 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
             if (k < (1u << cap_shift)) {
                 const size_t pos = ((size_t)cell << cap_shift) + k;
                 boxes[pos] = make_float4(x0, bw, y0, bh);
-                ids[pos] = id | (moi << RT_LCELL_ID_BITS);
+                reinterpret_cast<uint2*>(ids)[pos] = make_uint2(id | (moi << RT_LCELL_ID_BITS), __float_as_uint(zcull));
             }
         }
 }
@@ -3204,6 +3240,8 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     if (STATS && act) st.rays += 1;
     float qu, qv;
     light_uv(lp, o, qu, qv);
+    // the origin's depth, as k_lcell_bin takes the vertices'
+    const float depth = (pick3(o, lp.w) - lp.c_w) * (lp.c_w > lp.sun_w ? 1.0f : -1.0f);
     lds.ray[0][lane] = o.x, lds.ray[1][lane] = o.y, lds.ray[2][lane] = o.z;
     lds.ray[3][lane] = d.x, lds.ray[4][lane] = d.y, lds.ray[5][lane] = d.z;
     if (lane < 2u) lds.hit[lane] = 0u;
@@ -3266,10 +3304,11 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     };
     // One list entry against the rays of the current cell (quc: their coordinate, NaN for the others).
     float quc = nan;
-    auto entry = [&](float x0, float bw, float y0, float bh, uint32_t e) {
+    auto entry = [&](float x0, float bw, float y0, float bh, uint32_t e, float zcull) {
         // 0 <= q - x0 <= x1 - x0 as one unsigned comparison of the floats' bits: a negative difference
         // has its sign bit set and compares above every positive width; so does a NaN.
-        bool in = (__float_as_uint(quc - x0) <= __float_as_uint(bw)) & (__float_as_uint(qv - y0) <= __float_as_uint(bh));
+        bool in = (__float_as_uint(quc - x0) <= __float_as_uint(bw)) & (__float_as_uint(qv - y0) <= __float_as_uint(bh)) &
+                  (depth >= zcull);
         if (!ONE_OBJ) in = in & (((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u) != 0u);
         const unsigned long long m = __ballot(in);
         if (m == 0ull) return;
@@ -3283,12 +3322,12 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
             if (qu != qu) quc = nan;
         }
     };
-    auto four = [&](const f32x16_t& B, const f32x4_t& E, uint32_t cnt) {
+    auto four = [&](const f32x16_t& B, const f32x8_t& E, uint32_t cnt) {
         if (STATS && quc == quc) st.box += cnt;
-        entry(B[0], B[1], B[2], B[3], __float_as_uint(E[0]));
-        if (cnt > 1u) entry(B[4], B[5], B[6], B[7], __float_as_uint(E[1]));
-        if (cnt > 2u) entry(B[8], B[9], B[10], B[11], __float_as_uint(E[2]));
-        if (cnt > 3u) entry(B[12], B[13], B[14], B[15], __float_as_uint(E[3]));
+        entry(B[0], B[1], B[2], B[3], __float_as_uint(E[0]), E[1]);
+        if (cnt > 1u) entry(B[4], B[5], B[6], B[7], __float_as_uint(E[2]), E[3]);
+        if (cnt > 2u) entry(B[8], B[9], B[10], B[11], __float_as_uint(E[4]), E[5]);
+        if (cnt > 3u) entry(B[12], B[13], B[14], B[15], __float_as_uint(E[6]), E[7]);
     };
     unsigned long long todo = alive;
     while (todo != 0ull) {
@@ -3299,21 +3338,21 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         quc = mine ? qu : nan;
         const uint32_t beg = c << cap_shift, end = beg + sload1u(counts + c);
         // The lists are read four entries at a time through the scalar cache (a box is x0, x1 - x0, y0,
-        // y1 - y0), the next four while the present four are worked on: the address of the next read
+        // y1 - y0; an id comes with its entry's depth), the next four while the present four are worked on: the address of the next read
         // is made to depend on the present data (a width's sign bit, always clear), which keeps the
         // compiler from issuing it ahead of the wait for that data and then waiting for both.
         if (beg == end) continue;
         f32x16_t B0 = sload16(boxes + beg), B1 = B0;
-        f32x4_t E0 = sload4(ids + beg), E1 = E0;
+        f32x8_t E0 = sload8(ids + 2 * (size_t)beg), E1 = E0;
         for (uint32_t j = beg;;) {
             if ((alive & grp) == 0ull) break;
             uint32_t nx = j + 4u + (__float_as_uint(B0[1]) >> 31);
-            if (nx < end) B1 = sload16(boxes + nx), E1 = sload4(ids + nx);
+            if (nx < end) B1 = sload16(boxes + nx), E1 = sload8(ids + 2 * (size_t)nx);
             four(B0, E0, min(4u, end - j));
             j = nx;
             if (j >= end || (alive & grp) == 0ull) break;
             nx = j + 4u + (__float_as_uint(B1[1]) >> 31);
-            if (nx < end) B0 = sload16(boxes + nx), E0 = sload4(ids + nx);
+            if (nx < end) B0 = sload16(boxes + nx), E0 = sload8(ids + 2 * (size_t)nx);
             four(B1, E1, min(4u, end - j));
             j = nx;
             if (j >= end) break;
@@ -3871,6 +3910,8 @@ static LightCells light_cells(const SceneView& sv, const LightProj& lp) {
     lc.margin = 512.0f * 5.9604645e-8f * 1.7320508f * sv.scene_extent * 1.001f;
     lc.slope_u = 1.0f + std::fabs(lp.uc) + lp.uabs;
     lc.slope_v = 1.0f + std::fabs(lp.vc) + lp.vabs;
+    lc.away = lp.c_w > lp.sun_w ? 1.0f : -1.0f;
+    lc.depth_span = sv.scene_extent;
     return lc;
 }
 

@@ -22,6 +22,12 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def ctx():
+    # PyTorch wheels bundle a HIP runtime of their own (soname libamdhip64.so.7, like the system's).
+    # Loaded first, it is the copy the library binds to as well, and streams, events and pointers can
+    # pass between the two; loaded second, the process holds two runtimes that do not know each
+    # other's handles. The GPU tests take their device buffers and streams from torch.
+    import torch  # noqa: F401
+
     from raytracing_amd import Context
 
     c = Context(0)

@@ -172,6 +172,44 @@ def test_cells_with_triangles_edge_on_to_the_light(ctx, oracle, monkeypatch, kin
     _frames(ctx, oracle, objs, monkeypatch, [(160, 90, 2), (128, 72, 4)], sun=sun)
 
 
+def _layers(rng, axis, n, gaps):
+    """n stacks of triangles that lie across `axis` (0, 1 or 2), each stack a receiver with copies of
+    itself, shrunk and shifted a little, at the given gaps towards smaller coordinates of that axis:
+    seen from a sun down that axis the copies start where the receiver's shadow rays start."""
+    out = []
+    for _ in range(n):
+        c = np.array([rng.uniform(-4, 4), rng.uniform(-2.5, 2.5), rng.uniform(7, 13)])
+        size = rng.uniform(0.4, 2.5)
+        tri = rng.uniform(-1, 1, (3, 3)) * size
+        tri[:, axis] = rng.choice([0.0, 0.0, 1e-3, 0.05]) * rng.uniform(-1, 1, 3)   # flat, or nearly
+        depth = 0.0
+        for gap in gaps:
+            depth -= gap
+            t = tri * rng.uniform(0.5, 1.0) + rng.uniform(-0.1, 0.1, 3) * size
+            t[:, axis] = tri[:, axis] + depth
+            out.append(c + t)
+        out.append(c + tri)
+    v = np.array(out, dtype=np.float32)
+    v[..., 2] = np.maximum(v[..., 2], 0.5)
+    return v
+
+
+@pytest.mark.parametrize("axis,sun", [(2, (1.0, 2.0, -1.0e5)), (2, (3.0, 4.0, -30.0)), (1, (0.5, 1.0e5, 9.0)),
+                                      (0, (-60.0, 2.0, 8.0))])
+def test_cells_with_occluders_at_the_depth_of_the_rays(ctx, oracle, monkeypatch, axis, sun):
+    """A list entry is skipped by rays that start nearer the sun than the triangle lies. Here the
+    occluders lie at the very depth the shadow rays start from: coplanar copies, copies a few units
+    of rounding, 1e-5, 1e-3 and 0.1 in front, a ray's own triangle (distance zero, either sign after
+    rounding), and tilted triangles that cut through the stacks."""
+    rng = np.random.default_rng(31 + axis + int(abs(sun[0])))
+    stacks = _layers(rng, axis, 40, [0.0, 2e-6, 1e-5, 1e-3, 0.1])
+    cutters = _slivers(rng, 16, 6.0, 1.5, 7, 13)
+    pad = (-len(stacks) - len(cutters)) % 8     # whole leaves: every triangle takes the eight-wide test
+    fill = scenes.soup(pad + 64, 0x5EED0012)[0]["verts"].reshape(-1, 3, 3)
+    objs = [_as_object(np.concatenate([stacks, cutters, fill]).astype(np.float32))]
+    _frames(ctx, oracle, objs, monkeypatch, [(160, 90, 2), (96, 54, 4)], sun=sun)
+
+
 @pytest.mark.parametrize("shards", [2, 5])
 def test_cells_in_sharded_frames(soup200k, monkeypatch, shards):
     """A shard's rays are a fraction of the frame's, spread over all the light-space cells; the lists
