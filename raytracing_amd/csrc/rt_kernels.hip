@@ -3164,7 +3164,7 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
             const uint32_t k = atomicAdd(&counts[cell], 1u);
             if (k < (1u << cap_shift)) {
                 const size_t pos = ((size_t)cell << cap_shift) + k;
-                boxes[pos] = make_float4(x0, bw, y0, bh);
+                boxes[pos] = make_float4(x0, y0, bw, bh);
                 reinterpret_cast<uint2*>(ids)[pos] = make_uint2(id | (moi << RT_LCELL_ID_BITS), __float_as_uint(zcull));
             }
         }
@@ -3208,9 +3208,34 @@ __global__ __launch_bounds__(256) void k_lcell_check(const uint32_t* __restrict_
 
 struct ShadowCellsLds {
     float ray[6][64];       // origin and direction of the wave's rays
-    uint32_t queue[128];    // ring of (triangle entry << 6 | ray's lane) waiting for the exact test
+    alignas(512) uint32_t queue[128];   // ring of (triangle entry << 6 | ray's lane) waiting for the exact test
     uint32_t hit[2];        // rays the last batch of exact tests found occluded
 };
+static_assert(sizeof(uint32_t[128]) == 512, "ring_append wraps the ring's byte offset with a mask of 0x1fc");
+
+// The lanes of mask m append (e << 6 | lane) to the ring of 128 words at LDS address `ring` (a
+// multiple of 512), from position `tail` on, in lane order. Written out because the compiler turns
+// the same thing in C++ (ballot of a combined predicate, then a branch on the lane's own bit) into
+// twice the instructions: here the mask goes into exec as it is.
+__device__ __forceinline__ void ring_append(unsigned long long m, uint32_t tail, uint32_t e, uint32_t lane, uint32_t ring) {
+    uint32_t at, word;
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b32 exec_lo, %[mlo]\n\t"
+        "s_mov_b32 exec_hi, %[mhi]\n\t"
+        "v_mbcnt_lo_u32_b32 %[at], %[mlo], 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[at], %[mhi], %[at]\n\t"
+        "v_add_lshl_u32 %[at], %[at], %[tail], 2\n\t"
+        "v_and_or_b32 %[at], %[at], %[wrap], %[ring]\n\t"
+        "v_lshl_or_b32 %[word], %[e], 6, %[lane]\n\t"
+        "ds_write_b32 %[at], %[word]\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [saved] "=&s"(saved), [at] "=&v"(at), [word] "=&v"(word)
+        : [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [tail] "s"(tail), [wrap] "s"(0x1fcu), [ring] "v"(ring),
+          [e] "s"(e), [lane] "v"(lane)
+        : "memory");
+}
 
 template <bool STATS, bool ONE_OBJ>
 __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderParams p, LightProj lp,
@@ -3304,18 +3329,16 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     };
     // One list entry against the rays of the current cell (quc: their coordinate, NaN for the others).
     float quc = nan;
-    auto entry = [&](float x0, float bw, float y0, float bh, uint32_t e, float zcull) {
+    const uint32_t ring = (uint32_t)(uintptr_t)&lds.queue[0];   // an LDS address is the low half of the flat one
+    auto entry = [&](float x0, float y0, float bw, float bh, uint32_t e, float zcull) {
         // 0 <= q - x0 <= x1 - x0 as one unsigned comparison of the floats' bits: a negative difference
-        // has its sign bit set and compares above every positive width; so does a NaN.
-        bool in = (__float_as_uint(quc - x0) <= __float_as_uint(bw)) & (__float_as_uint(qv - y0) <= __float_as_uint(bh)) &
-                  (depth >= zcull);
-        if (!ONE_OBJ) in = in & (((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u) != 0u);
-        const unsigned long long m = __ballot(in);
+        // has its sign bit set and compares above every positive width; so does a NaN. One vote per
+        // comparison, the masks combined as scalars: each vote is then the comparison itself.
+        unsigned long long m = __ballot(__float_as_uint(quc - x0) <= __float_as_uint(bw)) &
+                               __ballot(__float_as_uint(qv - y0) <= __float_as_uint(bh)) & __ballot(depth >= zcull);
+        if (!ONE_OBJ) m &= __ballot(((objmask >> (e >> RT_LCELL_ID_BITS)) & 1u) != 0u);
         if (m == 0ull) return;
-        if (in) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            lds.queue[(tail + before) & 127u] = (e << 6) | lane;   // the object's bits fall off the top
-        }
+        ring_append(m, tail, e, lane, ring);   // the object's bits fall off the top of e << 6
         tail += (uint32_t)__builtin_popcountll(m);
         if (tail - head >= 64u) {
             flush(64u);
@@ -3337,7 +3360,7 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         todo &= ~grp;
         quc = mine ? qu : nan;
         const uint32_t beg = c << cap_shift, end = beg + sload1u(counts + c);
-        // The lists are read four entries at a time through the scalar cache (a box is x0, x1 - x0, y0,
+        // The lists are read four entries at a time through the scalar cache (a box is x0, y0, x1 - x0,
         // y1 - y0; an id comes with its entry's depth), the next four while the present four are worked on: the address of the next read
         // is made to depend on the present data (a width's sign bit, always clear), which keeps the
         // compiler from issuing it ahead of the wait for that data and then waiting for both.
@@ -3346,12 +3369,12 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         f32x8_t E0 = sload8(ids + 2 * (size_t)beg), E1 = E0;
         for (uint32_t j = beg;;) {
             if ((alive & grp) == 0ull) break;
-            uint32_t nx = j + 4u + (__float_as_uint(B0[1]) >> 31);
+            uint32_t nx = j + 4u + (__float_as_uint(B0[2]) >> 31);
             if (nx < end) B1 = sload16(boxes + nx), E1 = sload8(ids + 2 * (size_t)nx);
             four(B0, E0, min(4u, end - j));
             j = nx;
             if (j >= end || (alive & grp) == 0ull) break;
-            nx = j + 4u + (__float_as_uint(B1[1]) >> 31);
+            nx = j + 4u + (__float_as_uint(B1[2]) >> 31);
             if (nx < end) B0 = sload16(boxes + nx), E0 = sload8(ids + 2 * (size_t)nx);
             four(B1, E1, min(4u, end - j));
             j = nx;
