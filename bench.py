@@ -93,7 +93,7 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
     scene.render_device(p, frame.data_ptr(), None, sh)
     torch.cuda.synchronize()
     n = 3
-    events = [[new_event() for _ in range(7)] for _ in range(n)]
+    events = [[new_event() for _ in range(8)] for _ in range(n)]
     t0 = time.perf_counter()
     for i in range(n):
         scene.render_device_events(p, frame.data_ptr(), [e.value for e in events[i]], None, sh)
@@ -257,7 +257,7 @@ def main():
         assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
         return ms.value
 
-    phase_events = [[new_event() for _ in range(7)] for _ in range(args.steps)]
+    phase_events = [[new_event() for _ in range(8)] for _ in range(args.steps)]
 
     def step(i, timed_index=None):
         b = i % 2
@@ -336,7 +336,7 @@ def main():
         os.environ["RAYS_HIP_RASTER"] = "0"
         os.environ["RAYS_HIP_SHADOW"] = "walk"
         st_walk = scene.render_device_stats(p, frames[0].data_ptr())
-        walk_events = [[new_event() for _ in range(7)] for _ in range(args.steps)]
+        walk_events = [[new_event() for _ in range(8)] for _ in range(args.steps)]
         for i in range(args.warmup):
             scene.render_device(p, frames[0].data_ptr(), None, sh)
         fence()
@@ -382,43 +382,70 @@ def main():
         n_shadow_rank = st["rays"] - st["primary_rays"]
         projected = bool(st["camera_by_projection"])
         by_cells = bool(st["shadow_by_cells"])
-        alg_parts = None
-        if by_cells:
-            # k_shadow_cells, the frame's longest kernel: per shadow ray its sorted key (4 B), slot number
-            # (4 B), hit point (16 B) and state word read and written back (8 B); every list entry once
-            # (box 16 B + id 4 B), a count per cell (4 B), the triangles' data once (36 B each).
-            kernel, kernel_ms = "k_shadow_cells", phase_ms[2]
-            alg_parts = {"per_ray": 32 * n_shadow_rank, "list_entries": 20 * st["shadow_list_entries"],
-                         "cell_counts": 4 * st["shadow_list_cells"], "triangles": 36 * args.tris}
+        # the camera rays' main kernel alone: from event [7] (set-up and binning done) to event [1]
+        camera_kernel_ms = float(np.mean([elapsed_ms(ev[7], ev[1]) for ev in phase_events]))
+
+        def entry(kernel, kernel_ms, alg_parts, requested_bytes, flops, unit, units):
             alg_bytes = sum(alg_parts.values())
-            # what the loads ask the caches for: every wave reads its cells' lists (16 B per box test of a
-            # wave; the instrumented build counts box tests per unoccluded ray, so this is a lower bound)
-            # and 36 B of triangle data per pair tested
-            my_box, my_tri = st["box_tests"] - st["primary_box_tests"], st["tri_tests"] - st["primary_tri_tests"]
-            requested_bytes = alg_parts["per_ray"] + 36 * my_tri + 20 * my_box // 64
-        elif projected or phase_ms[2] > phase_ms[0]:
-            # k_wf_shadow: the sorted key of every sample slot in (4 B; slots without a shadow ray end
-            # there), per shadow ray its slot number (4 B), hit point (16 B) and state word read and
-            # written back (8 B), the wide tree and the triangle records once.
-            kernel, kernel_ms = "k_wf_shadow", phase_ms[2]
-            per_ray = 4 * n_samples_rank + 28 * n_shadow_rank
-            alg_bytes = per_ray + sizes["wide"] + sizes["recs"]
-            requested_bytes = per_ray + st["fetch_bytes"] - st["primary_fetch_bytes"]
-            my_box, my_tri = st["box_tests"] - st["primary_box_tests"], st["tri_tests"] - st["primary_tri_tests"]
+            achieved = alg_bytes / (kernel_ms * 1e-3)
+            return {
+                "bound": "hbm", "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK,
+                # HBM traffic needs hardware counters (rocprofv3 --pmc passes of this very command): not
+                # measured inside this process. The kept summaries are under profiles/.
+                "traffic": None,
+                "traffic_profile": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)",
+                "kernel_ms": kernel_ms, "launch_unit": unit, "units_per_launch": units,
+                "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_unit": alg_bytes / max(1, units),
+                "alg_bytes_parts": alg_parts,
+                "requested_bytes_per_launch": requested_bytes,
+                "requested_tb_per_s": requested_bytes / (kernel_ms * 1e-3) / 1e12,
+                "valu_tflops": flops / (kernel_ms * 1e-3) / 1e12,
+                "valu_frac": flops / (kernel_ms * 1e-3) / FP32_PEAK,
+            }
+
+        if projected:
+            # k_raster_tile: per entry of a tile's triangle list its id and prepared record in (4 + 96 B;
+            # the instrumented build counts them), per sample its record out (hit point + id 16 B, state
+            # 4 B, sort key 4 B), the normals/colours once. Nearest hits live in LDS: no bytes.
+            parts = {"tile_list_entries": st["primary_fetch_bytes"], "sample_records": 24 * n_samples_rank,
+                     "tri_data": sizes["tri_data"]}
+            camera = entry("k_raster_tile", camera_kernel_ms, parts, sum(parts.values()),
+                           FLOP_TRI * st["primary_tri_tests"] + FLOP_BOX * st["primary_box_tests"], "camera sample",
+                           n_samples_rank)
         else:
             # k_wf_primary: 24 B written per sample (hit point + id 16 B, state 4 B, sort key 4 B; camera
             # rays are generated on the device, 0 B in), the wide tree, the triangle records and the
             # normals/colours once.
-            kernel, kernel_ms = "k_wf_primary", phase_ms[0]
-            alg_bytes = 24 * n_samples_rank + sizes["wide"] + sizes["recs"] + sizes["tri_data"]
-            requested_bytes = 24 * n_samples_rank + st["primary_fetch_bytes"]
-            my_box, my_tri = st["primary_box_tests"], st["primary_tri_tests"]
-        # a light-space box test is 2 subtractions and 2 comparisons
-        alg_flops = (4 if by_cells else FLOP_BOX) * my_box + FLOP_TRI * my_tri
-        achieved = alg_bytes / (kernel_ms * 1e-3)
-        # HBM traffic needs hardware counters (rocprofv3 --pmc passes of this very command): not
-        # measured inside this process. The kept summaries are under profiles/.
-        traffic = None
+            parts = {"sample_records": 24 * n_samples_rank, "wide_tree": sizes["wide"], "triangle_records": sizes["recs"],
+                     "tri_data": sizes["tri_data"]}
+            camera = entry("k_wf_primary", camera_kernel_ms, parts, 24 * n_samples_rank + st["primary_fetch_bytes"],
+                           FLOP_BOX * st["primary_box_tests"] + FLOP_TRI * st["primary_tri_tests"], "camera sample",
+                           n_samples_rank)
+        my_box, my_tri = st["box_tests"] - st["primary_box_tests"], st["tri_tests"] - st["primary_tri_tests"]
+        if by_cells:
+            # k_shadow_cells: per shadow ray its sorted key (4 B), slot number (4 B), hit point (16 B) and
+            # state word read and written back (8 B); every list entry once (box 16 B, id 4 B, depth 4 B),
+            # a count per cell (4 B), the triangles' data once (36 B each).
+            parts = {"per_ray": 32 * n_shadow_rank, "list_entries": 24 * st["shadow_list_entries"],
+                     "cell_counts": 4 * st["shadow_list_cells"], "triangles": 36 * args.tris}
+            # what the loads ask the caches for: every wave reads its cells' lists (24 B per box test of a
+            # wave; the instrumented build counts box tests per unoccluded ray, so this is a lower bound)
+            # and 36 B of triangle data per pair tested; a light-space box test is 3 subtractions or
+            # comparisons and 2 more comparisons
+            shadow = entry("k_shadow_cells", phase_ms[2], parts, parts["per_ray"] + 36 * my_tri + 24 * my_box // 64,
+                           5 * my_box + FLOP_TRI * my_tri, "shadow ray", n_shadow_rank)
+        else:
+            # k_wf_shadow: the sorted key of every sample slot in (4 B; slots without a shadow ray end
+            # there), per shadow ray its slot number (4 B), hit point (16 B) and state word read and
+            # written back (8 B), the wide tree and the triangle records once.
+            parts = {"per_ray": 4 * n_samples_rank + 28 * n_shadow_rank, "wide_tree": sizes["wide"],
+                     "triangle_records": sizes["recs"]}
+            shadow = entry("k_wf_shadow", phase_ms[2], parts,
+                           parts["per_ray"] + st["fetch_bytes"] - st["primary_fetch_bytes"],
+                           FLOP_BOX * my_box + FLOP_TRI * my_tri, "shadow ray", n_shadow_rank)
+        # the frame's longest kernel first
+        roofline, roofline_other = (camera, shadow) if camera["kernel_ms"] >= shadow["kernel_ms"] else (shadow, camera)
         out = {
             "metric": "Mrays/s (1M-tri soup, 3840x2160 primary + shadow rays; camera rays' nearest hits by "
                       "projection of the triangles onto the sample grid, shadow rays against per-cell triangle "
@@ -457,23 +484,8 @@ def main():
                              if backend == "nccl" else "host-staged rehearsal") if world > 1 else None)),
                 "ranks_seen": ranks_seen,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel,
-                "achieved": achieved / 1e9,
-                "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK,
-                "traffic": traffic,
-                "traffic_profile": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)",
-                "kernel_ms": kernel_ms,
-                "alg_bytes_per_launch": alg_bytes,
-                "alg_bytes_parts": alg_parts,
-                "requested_bytes_per_launch": requested_bytes,
-                "requested_tb_per_s": requested_bytes / (kernel_ms * 1e-3) / 1e12,
-                "valu_tflops": alg_flops / (kernel_ms * 1e-3) / 1e12,
-                "valu_frac": alg_flops / (kernel_ms * 1e-3) / FP32_PEAK,
-            },
+            "roofline": roofline,
+            "roofline_second_kernel": roofline_other,
         }
         if elapsed_in_flight is not None:
             out["two_frames_in_flight"] = {

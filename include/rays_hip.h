@@ -108,7 +108,7 @@ typedef struct {
 } rt_stats;
 
 /* Number of events rt_render_device_events records. */
-#define RT_RENDER_EVENTS 7
+#define RT_RENDER_EVENTS 8
 
 #define RT_TILE 32u   /* screen tiles are RT_TILE x RT_TILE pixels                           */
 
@@ -202,8 +202,11 @@ int  rt_render_device(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint
  * kernel records [0] before and [1]..[4] after it. Frames with diffuse scattering also record [5]
  * before and [6] after the launches that trace the secondary rays (all levels of the frame's last
  * run of tiles; [3] then follows the shadow rays of those levels); other frames record [5] and
- * [6] together with [4]. With two frames in flight [0]..[3] are recorded on the scene's own stream
- * and the phases of consecutive frames overlap. For measurement; no reference counterpart. */
+ * [6] together with [4]. [7] lies between [0] and [1]: the camera rays' set-up (camera table,
+ * binning of the triangles by screen tile) is done and their main kernel is next; a one-kernel
+ * frame records it with the rest. With two frames in flight [0]..[3] and [7] are recorded on the
+ * scene's own stream and the phases of consecutive frames overlap. For measurement; no reference
+ * counterpart. */
 int  rt_render_device_events(rt_scene*, const rt_render_params*, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                              void* stream, void* const* events, int n_events);
 /* As rt_render_device, from an instrumented build of the same kernels; synchronises and fills

@@ -257,7 +257,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                   bool* projected = nullptr, DevStats* bounce_stats = nullptr, bool* lists_built = nullptr) {
     hipStream_t ws = stream;   // where the phases before the resolve kernel run (see in_flight below)
     auto mark = [&](int k) -> hipError_t {
-        return events ? hipEventRecord((hipEvent_t)events[k], k <= 3 ? ws : stream) : hipSuccess;
+        return events ? hipEventRecord((hipEvent_t)events[k], (k <= 3 || k == 7) ? ws : stream) : hipSuccess;
     };
     uint32_t spp = 0;
     int rc = check_render_params(p, &spp);
@@ -301,7 +301,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (!pipeline) {
         HIP_TRY(mark(0));
         HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
-        for (int k = 1; k < RT_RENDER_EVENTS; ++k) HIP_TRY(mark(k));  // [5], [6] with the rest
+        for (int k = 1; k < RT_RENDER_EVENTS; ++k) HIP_TRY(mark(k));  // [5], [6], [7] with the rest
         if (primary_stats && d_stats) {
             HIP_TRY(hipStreamSynchronize(stream));
             HIP_TRY(hipMemcpy(primary_stats, d_stats, sizeof(DevStats), hipMemcpyDeviceToHost));
@@ -533,6 +533,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         dp.n_tiles = std::min(run_tiles, total_tiles - first);
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
         const LightProj lp = light_projection(s, p, n_slots);
+        if (first == 0) HIP_TRY(mark(7));   // set-up and binning done: the camera rays' main kernel is next
         if (raster_by_tile) {
             HIP_TRY(rtk::raster_tiles(s->view, dp, lp, d_list, w.cam_table, w.bin_offsets, w.bin_list, w.bin_recs, w.samp,
                                       w.state, w.keys[0], d_stats, ws));

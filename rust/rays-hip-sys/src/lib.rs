@@ -5,7 +5,7 @@ use std::os::raw::{c_char, c_int, c_void};
 pub const RT_MISS: u32 = 0xFFFF_FFFF;
 pub const RT_BUILD_DEVICE: u32 = 1;
 pub const RT_TILE: u32 = 32;
-pub const RT_RENDER_EVENTS: c_int = 5;
+pub const RT_RENDER_EVENTS: c_int = 8;
 
 #[repr(C)]
 pub struct rt_ctx {

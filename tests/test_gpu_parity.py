@@ -521,7 +521,7 @@ def test_render_events_stats_and_sizes(soup_pair):
     ref, ids = g.render(p, want_hit_ids=True)
     hip = ctypes.CDLL("libamdhip64.so")
     evs = []
-    for _ in range(7):
+    for _ in range(8):
         e = ctypes.c_void_p()
         assert hip.hipEventCreate(ctypes.byref(e)) == 0
         evs.append(e)
@@ -531,14 +531,14 @@ def test_render_events_stats_and_sizes(soup_pair):
         g.render_device_events(p, frame.data_ptr(), [e.value for e in evs], None, stream.cuda_stream)
     stream.synchronize()
     assert np.array_equal(frame.cpu().numpy(), ref)
-    for k in range(4):
+    for a, b in ((0, 7), (7, 1), (1, 2), (2, 3), (3, 4)):   # [7] lies between [0] and [1]
         ms = ctypes.c_float()
-        assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[k], evs[k + 1]) == 0
+        assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[a], evs[b]) == 0
         assert ms.value >= 0.0
     for e in evs:
         hip.hipEventDestroy(e)
     with pytest.raises(Exception):
-        g.render_device_events(p, frame.data_ptr(), [0] * 7, None, stream.cuda_stream)
+        g.render_device_events(p, frame.data_ptr(), [0] * 8, None, stream.cuda_stream)
     with pytest.raises(Exception):
         g.render_device_events(p, frame.data_ptr(), [e.value for e in evs[:5]], None, stream.cuda_stream)
 

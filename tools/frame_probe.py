@@ -22,7 +22,7 @@ def ms(a, b):
 sh = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
     scene.render_device(p, frame.data_ptr(), None, sh)
-evs = [[ev() for _ in range(5)] for _ in range(8)]
+evs = [[ev() for _ in range(8)] for _ in range(8)]   # RT_RENDER_EVENTS handles a frame
 for e in evs:
     scene.render_device_events(p, frame.data_ptr(), [x.value for x in e], None, sh)
 torch.cuda.synchronize()
