@@ -1958,10 +1958,17 @@ __device__ __forceinline__ void light_uv(const LightProj& lp, rt_f3 pos, float& 
     qv = (v - lp.v0) * lp.vscale;
 }
 
-// Light-space sort key of a shadow ray's origin: its light-space coordinates interleaved.
+// Light-space sort key of a shadow ray's origin: its light-space coordinates interleaved. The key
+// only says which cell's rays (and which cell's triangle list) a ray goes with, so the hardware
+// reciprocal will do: it moves a coordinate by a few millionths of its 65,536 units, and a ray that
+// lands in the neighbouring cell for it finds the same triangles there, since every triangle's patch
+// is grown by half a unit for roundings of this kind (k_lcell_bin).
 __device__ __forceinline__ uint32_t light_key(const LightProj& lp, rt_f3 pos) {
-    float fu, fv;
-    light_uv(lp, pos, fu, fv);
+    const float pw = pick3(pos, lp.w);
+    const float rw = __builtin_amdgcn_rcpf(pw - lp.sun_w);
+    const float dw = pw - lp.c_w;
+    const float fu = (((pick3(pos, lp.a1) - lp.c_a1) - lp.uc * dw) * rw - lp.u0) * lp.uscale;
+    const float fv = (((pick3(pos, lp.a2) - lp.c_a2) - lp.vc * dw) * rw - lp.v0) * lp.vscale;
     const float qu = fminf(fmaxf(fu, 0.0f), 65535.0f);
     const float qv = fminf(fmaxf(fv, 0.0f), 65535.0f);
     uint32_t key = spread16((uint32_t)qu) | (spread16((uint32_t)qv) << 1);
@@ -2659,15 +2666,11 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Position (subx, suby) of sub-sample s on the n x n grid inside a pixel: the inverse of sample_of.
-__device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t s, uint32_t* subx, uint32_t* suby) {
-    if (grid == 2) {
-        *subx = s & 1u;
-        *suby = (s == 1u || s == 2u) ? 1u : 0u;
-    } else {
-        *subx = s % grid;
-        *suby = s / grid;
-    }
+// Position (subx, suby) of sub-sample s on the n x n grid inside a pixel, n = 1 << shift: the inverse
+// of sample_of.
+__device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t shift, uint32_t s, uint32_t* subx, uint32_t* suby) {
+    *subx = s & (grid - 1u);
+    *suby = grid == 2u ? ((s == 1u || s == 2u) ? 1u : 0u) : s >> shift;
 }
 
 // One half-plane along one row of the tile, F(column) = fma(dx[column], gx, r): the columns that
@@ -2679,14 +2682,17 @@ __device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t s, uint32_t* 
 // lies far outside the tile. With RT_CLIP_SLACK = 1/16 column on either side the cut keeps every
 // passing column. An x that is NaN (gx == 0 with r == 0) cuts nothing.
 #define RT_CLIP_SLACK 0.0625f
-__device__ __forceinline__ void row_clip(float gx, float x, int& lo, int& hi) {
-    if (gx > 0.0f) {
-        const float f = ceilf(x - RT_CLIP_SLACK);
-        if (f > (float)lo) lo = f <= (float)hi ? (int)f : hi + 1;
-    } else if (gx < 0.0f) {
-        const float c = floorf(x + RT_CLIP_SLACK);
-        if (c < (float)hi) hi = c >= (float)lo ? (int)c : lo - 1;
-    }
+// The run [lo, hi] of columns is kept in floats and cut without a branch: a half-plane with gx > 0
+// raises lo to ceil(x - slack), one with gx < 0 lowers hi to floor(x + slack). `raise` is 0 for gx > 0
+// and -inf otherwise, `lower` 0 for gx < 0 and +inf otherwise (set once per triangle: see row_pens),
+// so the side that does not apply becomes -inf / +inf, or NaN, and max / min pass it over.
+__device__ __forceinline__ void row_clip(float x, float raise, float lower, float& lo, float& hi) {
+    lo = fmaxf(lo, ceilf(x - RT_CLIP_SLACK) + raise);
+    hi = fminf(hi, floorf(x + RT_CLIP_SLACK) + lower);
+}
+__device__ __forceinline__ void row_pens(float gx, float& raise, float& lower) {
+    raise = gx > 0.0f ? 0.0f : -RT_INF;
+    lower = gx < 0.0f ? 0.0f : RT_INF;
 }
 
 #ifndef RT_RTILE_WAVES
@@ -2871,6 +2877,8 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             const int sr1 = has_seg ? min((int)((bw2 >> 15) & 31u), sr0 + (int)RT_SEG - 1) : sr0 - 1;
             const float ku = -ax * __builtin_amdgcn_rcpf(q.gu.x), kv = -ax * __builtin_amdgcn_rcpf(q.gv.x),
                         kw = -ax * __builtin_amdgcn_rcpf(q.gw.x);
+            float raise_u, lower_u, raise_v, lower_v, raise_w, lower_w;
+            row_pens(q.gu.x, raise_u, lower_u), row_pens(q.gv.x, raise_v, lower_v), row_pens(q.gw.x, raise_w, lower_w);
             // Every lane goes down the rows of its segment: per row, the run of columns that pass all
             // three half-planes (an exact run: see row_clip), queued in pieces of RT_RUN samples.
             for (int row = sr0; __ballot(row <= sr1) != 0ull; ++row) {
@@ -2880,11 +2888,15 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                     const float dy = lds.dy[row];
                     const float ru = __builtin_fmaf(dy, q.gu.y, q.gu.z), rv = __builtin_fmaf(dy, q.gv.y, q.gv.z),
                                 rw = __builtin_fmaf(dy, q.gw.y, q.gw.z);
-                    row_clip(q.gu.x, __builtin_fmaf(ru, ku, off), lo, hi);
-                    row_clip(q.gv.x, __builtin_fmaf(rv, kv, off), lo, hi);
-                    row_clip(q.gw.x, __builtin_fmaf(rw, kw, off), lo, hi);
+                    float flo = (float)lo, fhi = (float)hi;
+                    row_clip(__builtin_fmaf(ru, ku, off), raise_u, lower_u, flo, fhi);
+                    row_clip(__builtin_fmaf(rv, kv, off), raise_v, lower_v, flo, fhi);
+                    row_clip(__builtin_fmaf(rw, kw, off), raise_w, lower_w, flo, fhi);
                     // a half-plane that does not depend on the column passes the whole row or none of it
-                    if ((q.gu.x == 0.0f && ru < 0.0f) || (q.gv.x == 0.0f && rv < 0.0f) || (q.gw.x == 0.0f && rw < 0.0f)) hi = lo - 1;
+                    const bool none = (q.gu.x == 0.0f && ru < 0.0f) || (q.gv.x == 0.0f && rv < 0.0f) || (q.gw.x == 0.0f && rw < 0.0f);
+                    // lo and hi stay within the box's columns whenever the run is not empty
+                    if (flo <= fhi && !none) lo = (int)flo, hi = (int)fhi;
+                    else hi = lo - 1;
                 }
                 while (true) {
                     const bool has = lo <= hi;
@@ -2915,7 +2927,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     // The records of the tile's samples, in slot order: what k_wf_primary stores.
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
     for (uint32_t k = threadIdx.x; k < RT_RTILE * RT_RTILE; k += 64u * RT_RTILE_GROUP) {
-        const uint32_t pl = k / spp, s = k % spp;      // pixel of the raster tile (Morton number), sample
+        const uint32_t pl = k >> (2u * gs), s = k & (spp - 1u);   // pixel of the raster tile (Morton number), sample: spp = g * g, g a power of two
         uint32_t pxl = 0, pyl = 0;
 #pragma unroll
         for (int bit = 0; bit < 5; ++bit) {
@@ -2923,8 +2935,8 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             pyl |= ((pl >> (2 * bit + 1)) & 1u) << bit;
         }
         uint32_t subx, suby;
-        sample_pos(g, s, &subx, &suby);
-        const uint32_t sul = pxl * g + subx, swl = pyl * g + suby;   // sample inside the tile
+        sample_pos(g, gs, s, &subx, &suby);
+        const uint32_t sul = (pxl << gs) + subx, swl = (pyl << gs) + suby;   // sample inside the tile
         const uint32_t x = ((uint32_t)su0 + sul) >> gs, y = ((uint32_t)sw0 + swl) >> gs;
         const bool inside = x < p.width && y < p.height;
         const unsigned long long key = inside ? lds.z[swl * RT_RTILE + sul] : RT_ZKEY_NONE;
