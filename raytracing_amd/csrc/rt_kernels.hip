@@ -3401,51 +3401,94 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     }
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_wf_resolve(SceneView sv, DevRenderParams p,
-                                                      const uint32_t* __restrict__ tile_list,
-                                                      const float4* __restrict__ samp,
-                                                      const uint32_t* __restrict__ state, uint8_t* __restrict__ rgba8,
-                                                      uint32_t* __restrict__ hit_ids) {
-    __shared__ float s_col[3 * BLOCK];
-    const PixelMap<BLOCK> pm(p, tile_list);
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    const float4 a = samp[slot];
-    const uint32_t stt = state[slot];
-    const uint32_t tri = __float_as_uint(a.w);
-    const bool hit_any = (stt & RT_ST_HIT) != 0u;
-    Col color{0.0f, 0.0f, 0.0f};
-    if (hit_any) {
-        // src/main.rs:176-241 on the stored hit point: the same operations as in k_render.
-        const float* td = sv.tri_data + 6 * (size_t)tri;
-        const rt_f3 normal = ld3(td);
-        const Col tcol = Col{td[3], td[4], td[5]};
-        const rt_f3 pos = f3(a.x, a.y, a.z);
-        const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-        const rt_f3 sun_dir = g_normalize(sun - pos);
-        if ((stt & RT_ST_LIT) && !(stt & RT_ST_OCC))
-            color = cmul(tcol, g_dot(normal, sun_dir) * sv.objs[stt >> 8].albedo);
-        color = gamma22(color);
-    } else {
-        color = pm.inside ? sky() : Col{0.0f, 0.0f, 0.0f};
+// Splits the bits of a pixel's Morton number inside its tile into column and row.
+__device__ __forceinline__ void morton_xy(uint32_t m, uint32_t& x, uint32_t& y) {
+    x = 0, y = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        x |= ((m >> (2 * b)) & 1u) << b;
+        y |= ((m >> (2 * b + 1)) & 1u) << b;
     }
-    const uint32_t spp = p.spp;
-    if (hit_ids && pm.inside) hit_ids[((uint64_t)pm.y * p.width + pm.x) * spp + pm.s] = tri;
-    s_col[3 * threadIdx.x + 0] = color.r;
-    s_col[3 * threadIdx.x + 1] = color.g;
-    s_col[3 * threadIdx.x + 2] = color.b;
-    __syncthreads();
-    if (pm.s == 0 && pm.inside) {
-        Col acc = color;
-        for (uint32_t k = 1; k < spp; ++k) {
-            const float* c = &s_col[3 * (threadIdx.x + k)];
-            acc = cadd(acc, Col{c[0], c[1], c[2]});
+}
+
+// One wave shades 64 * RT_RESOLVE_SLOTS consecutive sample slots, lane l the slots l, l + 64, ...: the
+// loads of all of a lane's slots are on their way before the first is used (a kernel with one slot
+// per lane is bound by the two dependent loads of each wave, record then normal and colour, not by
+// bytes), each load is a contiguous kilobyte, and the samples of a pixel (spp consecutive slots, spp a
+// power of two up to 64) meet in one wave. A slot's place in its tile is tile part + slot part + lane
+// part without carries between them, so its Morton number splits into three that are or-ed together,
+// the first two on the scalar side.
+#define RT_RESOLVE_SLOTS 4
+__global__ __launch_bounds__(64) void k_wf_resolve(SceneView sv, DevRenderParams p, const uint32_t* __restrict__ tile_list,
+                                                   const float4* __restrict__ samp, const uint32_t* __restrict__ state,
+                                                   uint8_t* __restrict__ rgba8, uint32_t* __restrict__ hit_ids) {
+    constexpr uint32_t K = RT_RESOLVE_SLOTS, PER = 64u * K;
+    __shared__ float s_col[3 * PER];
+    const uint32_t lane = threadIdx.x, spp = p.spp, ss = 31u - (uint32_t)__builtin_clz(spp);
+    // PER divides a tile's RT_TILE * RT_TILE * spp slots: (1024 / PER) << ss waves a tile
+    const uint32_t wshift = ss + 2u;
+    static_assert(RT_TILE * RT_TILE / PER == 4u, "waves per tile are taken as 4 * spp");
+    const uint32_t launch_tile = blockIdx.x >> wshift, in_tile = blockIdx.x & ((1u << wshift) - 1u);
+    const uint32_t local_tile = p.tile_first + launch_tile;
+    const uint32_t tile = (tile_list && launch_tile < p.n_tiles) ? tile_list[local_tile] : local_tile;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t slot0 = blockIdx.x * PER + lane;
+    float4 a[K];
+    uint32_t stt[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) a[k] = samp[slot0 + 64u * k], stt[k] = state[slot0 + 64u * k];
+    rt_f3 normal[K];
+    Col tcol[K];
+    float albedo[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        normal[k] = f3(0.0f, 0.0f, 0.0f), tcol[k] = Col{0.0f, 0.0f, 0.0f}, albedo[k] = 0.0f;
+        if (stt[k] & RT_ST_HIT) {
+            const float* td = sv.tri_data + 6 * (size_t)__float_as_uint(a[k].w);
+            normal[k] = ld3(td);
+            tcol[k] = Col{td[3], td[4], td[5]};
+            albedo[k] = sv.objs[stt[k] >> 8].albedo;
         }
+    }
+    uint32_t ax, ay, lx, ly;
+    morton_xy((in_tile * PER) >> ss, ax, ay);
+    morton_xy(lane >> ss, lx, ly);
+    const uint32_t s = lane & (spp - 1u);
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    uint32_t x[K], y[K];
+    bool inside[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        uint32_t kx, ky;
+        morton_xy((64u * k) >> ss, kx, ky);
+        x[k] = tx * RT_TILE + (ax | kx | lx), y[k] = ty * RT_TILE + (ay | ky | ly);
+        inside[k] = x[k] < p.width && y[k] < p.height;
+        const uint32_t tri = __float_as_uint(a[k].w);
+        Col color{0.0f, 0.0f, 0.0f};
+        if (stt[k] & RT_ST_HIT) {
+            // src/main.rs:176-241 on the stored hit point: the same operations as in k_render.
+            const rt_f3 sun_dir = g_normalize(sun - f3(a[k].x, a[k].y, a[k].z));
+            if ((stt[k] & RT_ST_LIT) && !(stt[k] & RT_ST_OCC)) color = cmul(tcol[k], g_dot(normal[k], sun_dir) * albedo[k]);
+            color = gamma22(color);
+        } else {
+            color = inside[k] ? sky() : Col{0.0f, 0.0f, 0.0f};
+        }
+        if (hit_ids && inside[k]) hit_ids[((uint64_t)y[k] * p.width + x[k]) * spp + s] = tri;
+        float* c = &s_col[3 * (64u * k + lane)];
+        c[0] = color.r, c[1] = color.g, c[2] = color.b;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        if (s != 0u || !inside[k]) continue;
+        const float* c = &s_col[3 * (64u * k + lane)];
+        Col acc = Col{c[0], c[1], c[2]};
+        for (uint32_t j = 1; j < spp; ++j) acc = cadd(acc, Col{c[3 * j], c[3 * j + 1], c[3 * j + 2]});
         acc = cdiv(acc, (float)spp);
         const uint32_t px = to_u8(acc.r) | (to_u8(acc.g) << 8) | (to_u8(acc.b) << 16) | 0xff000000u;
         size_t off;
-        if (p.compact) off = ((size_t)pm.local_tile * RT_TILE * RT_TILE + (size_t)pm.my * RT_TILE + pm.mx) * 4;
-        else off = ((size_t)pm.y * p.width + pm.x) * 4;
+        if (p.compact) off = ((size_t)local_tile * RT_TILE * RT_TILE + (size_t)(y[k] - ty * RT_TILE) * RT_TILE + (x[k] - tx * RT_TILE)) * 4;
+        else off = ((size_t)y[k] * p.width + x[k]) * 4;
         *reinterpret_cast<uint32_t*>(rgba8 + off) = px;
     }
 }
@@ -3990,10 +4033,9 @@ hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const Lig
 
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s) {
-    const uint32_t blocks = p.n_tiles * ((RT_TILE * RT_TILE) / (RT_BLOCK / p.spp));
+    const uint32_t blocks = p.n_tiles * (RT_TILE * RT_TILE / (64u * RT_RESOLVE_SLOTS)) * p.spp;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_wf_resolve<RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, d_tile_list, d_samp, d_state,
-                       d_rgba8, d_hit_ids);
+    hipLaunchKernelGGL(k_wf_resolve, dim3(blocks), dim3(64), 0, s, sv, p, d_tile_list, d_samp, d_state, d_rgba8, d_hit_ids);
     return hipGetLastError();
 }
 
