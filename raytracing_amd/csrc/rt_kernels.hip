@@ -2695,6 +2695,9 @@ __device__ __forceinline__ void row_pens(float gx, float& raise, float& lower) {
     lower = gx < 0.0f ? 0.0f : RT_INF;
 }
 
+#ifndef RT_RECORD_ROUND
+#define RT_RECORD_ROUND 4   // samples a lane writes the records of at a time
+#endif
 #ifndef RT_RTILE_WAVES
 #define RT_RTILE_WAVES 3
 #endif
@@ -2926,36 +2929,53 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     __syncthreads();   // both waves' nearest hits are in
     // The records of the tile's samples, in slot order: what k_wf_primary stores.
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-    for (uint32_t k = threadIdx.x; k < RT_RTILE * RT_RTILE; k += 64u * RT_RTILE_GROUP) {
-        const uint32_t pl = k >> (2u * gs), s = k & (spp - 1u);   // pixel of the raster tile (Morton number), sample: spp = g * g, g a power of two
-        uint32_t pxl = 0, pyl = 0;
+    // Four samples a lane at a time: their nearest hits are read and their triangles' normals asked for
+    // before the first record is worked out, so that a lane waits for device memory once in four samples
+    // (the normal's address comes out of the nearest-hit word: two dependent reads per sample).
+    constexpr uint32_t U = RT_RECORD_ROUND;
+    static_assert(RT_RTILE * RT_RTILE % (64u * RT_RTILE_GROUP * U) == 0, "the tile's samples are dealt out in rounds of U per lane");
+    for (uint32_t k0 = threadIdx.x; k0 < RT_RTILE * RT_RTILE; k0 += 64u * RT_RTILE_GROUP * U) {
+        uint32_t sul[U], swl[U];
+        bool inside[U], hit_any[U];
+        HitD hs[U];
+        rt_f3 normal[U];
 #pragma unroll
-        for (int bit = 0; bit < 5; ++bit) {
-            pxl |= ((pl >> (2 * bit)) & 1u) << bit;
-            pyl |= ((pl >> (2 * bit + 1)) & 1u) << bit;
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t k = k0 + u * 64u * RT_RTILE_GROUP;
+            const uint32_t pl = k >> (2u * gs), s = k & (spp - 1u);   // pixel of the raster tile (Morton number), sample: spp = g * g, g a power of two
+            uint32_t pxl = 0, pyl = 0;
+#pragma unroll
+            for (int bit = 0; bit < 5; ++bit) {
+                pxl |= ((pl >> (2 * bit)) & 1u) << bit;
+                pyl |= ((pl >> (2 * bit + 1)) & 1u) << bit;
+            }
+            uint32_t subx, suby;
+            sample_pos(g, gs, s, &subx, &suby);
+            sul[u] = (pxl << gs) + subx, swl[u] = (pyl << gs) + suby;   // sample inside the tile
+            const uint32_t x = ((uint32_t)su0 + sul[u]) >> gs, y = ((uint32_t)sw0 + swl[u]) >> gs;
+            inside[u] = x < p.width && y < p.height;
+            const unsigned long long key = inside[u] ? lds.z[swl[u] * RT_RTILE + sul[u]] : RT_ZKEY_NONE;
+            hit_any[u] = key != RT_ZKEY_NONE;
+            hs[u].tri = hit_any[u] ? (uint32_t)key : 0u;
+            hs[u].t = hit_any[u] ? __uint_as_float((uint32_t)(key >> 32)) : 0.0f;
+            hs[u].u = hs[u].v = 0.0f;
+            hs[u].obj = 0;
+            while (hs[u].obj + 1 < sv.n_objs && hs[u].tri >= sv.objs[hs[u].obj].tri_base + sv.objs[hs[u].obj].n_tris) ++hs[u].obj;
+            normal[u] = ld3(sv.tri_data + 6 * (size_t)hs[u].tri);
         }
-        uint32_t subx, suby;
-        sample_pos(g, gs, s, &subx, &suby);
-        const uint32_t sul = (pxl << gs) + subx, swl = (pyl << gs) + suby;   // sample inside the tile
-        const uint32_t x = ((uint32_t)su0 + sul) >> gs, y = ((uint32_t)sw0 + swl) >> gs;
-        const bool inside = x < p.width && y < p.height;
-        const unsigned long long key = inside ? lds.z[swl * RT_RTILE + sul] : RT_ZKEY_NONE;
-        const bool hit_any = key != RT_ZKEY_NONE;
-        HitD hs;
-        hs.tri = hit_any ? (uint32_t)key : 0u;
-        hs.t = hit_any ? __uint_as_float((uint32_t)(key >> 32)) : 0.0f;
-        hs.u = hs.v = 0.0f;
-        hs.obj = 0;
-        while (hs.obj + 1 < sv.n_objs && hs.tri >= sv.objs[hs.obj].tri_base + sv.objs[hs.obj].n_tris) ++hs.obj;
-        const rt_f3 d = f3(lds.dx[sul], lds.dy[swl], 1.0f);
-        const Surface sf = surface_of(sv, hs, o, d);
-        const rt_f3 sun_dir = g_normalize(sun - sf.pos);
-        const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
-        const uint32_t slot = slot_base + k;
-        samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(hit_any ? hs.tri : RT_MISS));
-        state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
-        keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
-        if (STATS) st.rays += inside ? 1u : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t k = k0 + u * 64u * RT_RTILE_GROUP;
+            const rt_f3 d = f3(lds.dx[sul[u]], lds.dy[swl[u]], 1.0f);
+            const rt_f3 pos = (o + d * hs[u].t) + (normal[u] * 0.00001f);   // as surface_of has it
+            const rt_f3 sun_dir = g_normalize(sun - pos);
+            const bool lit = hit_any[u] && g_dot(normal[u], sun_dir) > 0.0f;
+            const uint32_t slot = slot_base + k;
+            samp[slot] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(hit_any[u] ? hs[u].tri : RT_MISS));
+            state[slot] = (hit_any[u] ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs[u].obj << 8);
+            keys[slot] = lit ? light_key(lp, pos) : 0xFFFFFFFFu;
+            if (STATS) st.rays += inside[u] ? 1u : 0u;
+        }
     }
     if (STATS) flush_stats(st, stats);
 }
