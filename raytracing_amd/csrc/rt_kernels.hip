@@ -2599,20 +2599,35 @@ __global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_to
 }
 
 // offsets[i] = counts[0] + ... + counts[i - 1] for i = 0 .. n (offsets[n] = the total); counts are
-// set to zero. One workgroup of 1024 threads.
+// set to zero. One workgroup of 1024 threads, 32 consecutive counters a thread and stretch (the tiles
+// of a 3840 x 2160 x 4 frame are one stretch: the kernel's time is the latency of a stretch's loads,
+// two barriers and stores, times the stretches).
+#define RT_SCAN_PER 32u
 __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ offsets) {
     __shared__ uint32_t s_wave[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t carry = 0;   // sum of everything before the current stretch of 4096 counters
-    for (uint32_t first = 0; first < n; first += 4096u) {
-        const uint32_t i = first + 4u * t;
-        uint32_t c[4];
+    uint32_t carry = 0;   // sum of everything before the current stretch
+    for (uint32_t first = 0; first < n; first += 1024u * RT_SCAN_PER) {
+        const uint32_t i = first + RT_SCAN_PER * t;
+        uint32_t c[RT_SCAN_PER];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c[k] = i + k < n ? counts[i + k] : 0u;
-            if (i + k < n) counts[i + k] = 0u;
+        for (uint32_t q = 0; q < RT_SCAN_PER; q += 4u) {
+            if (i + q + 3u < n) {
+                uint4* p4 = reinterpret_cast<uint4*>(counts + i + q);   // i + q is a multiple of four
+                const uint4 v = *p4;
+                c[q] = v.x, c[q + 1u] = v.y, c[q + 2u] = v.z, c[q + 3u] = v.w;
+                *p4 = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+#pragma unroll
+                for (uint32_t k = q; k < q + 4u; ++k) {
+                    c[k] = i + k < n ? counts[i + k] : 0u;
+                    if (i + k < n) counts[i + k] = 0u;
+                }
+            }
         }
-        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < RT_SCAN_PER; ++k) mine += c[k];
         uint32_t incl = mine;   // inclusive sum over the wave's lanes
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -2629,9 +2644,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ coun
         }
         uint32_t run = before + incl - mine;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i + k < n) offsets[i + k] = run;
-            run += c[k];
+        for (uint32_t q = 0; q < RT_SCAN_PER; q += 4u) {
+            uint32_t r[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) r[k] = run, run += c[q + k];
+            if (i + q + 3u < n) {
+                *reinterpret_cast<uint4*>(offsets + i + q) = make_uint4(r[0], r[1], r[2], r[3]);
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k)
+                    if (i + q + k < n) offsets[i + q + k] = r[k];
+            }
         }
         carry += total;
         __syncthreads();
