@@ -3655,8 +3655,11 @@ struct TreeSource {
             dkeys[i] = lit ? light_key(lp, s2.pos) : 0xFFFFFFFFu;
             spawn = next_queue != nullptr && s2.reflectivity > 0.0f;
         }
-        // The lanes that emit in this turn and bounce on append to the wave's list together.
+        // The lanes that emit in this turn and bounce on append to the wave's list together. The list's
+        // length is written by one lane and read by all in the next turn: the hardware serves a wave's
+        // LDS instructions in order, the fences keep the compiler from moving or caching them.
         const unsigned long long mask = __ballot(spawn);
+        wave_lds_sync();
         if (spawn) {
             const uint32_t lane = threadIdx.x & 63u;
             const uint32_t base = s_q[RT_QUEUE_LDS];
@@ -3664,6 +3667,7 @@ struct TreeSource {
             s_q[base + rank] = j;
             if (rank == 0) s_q[RT_QUEUE_LDS] = base + (uint32_t)__builtin_popcountll(mask);
         }
+        wave_lds_sync();
     }
     // Whole wave: writes the collected rays out once there are 32 (or any, at the end), one atomic
     // per write. A turn adds at most 64, so the list never passes 95.
@@ -3675,7 +3679,9 @@ struct TreeSource {
         if (lane == 0) base = atomicAdd(next_count, n);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         for (uint32_t i = lane; i < n; i += 64u) next_queue[base + i] = s_q[i];
+        wave_lds_sync();
         if (lane == 0) s_q[RT_QUEUE_LDS] = 0u;
+        wave_lds_sync();
     }
 };
 

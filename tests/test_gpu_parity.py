@@ -566,6 +566,21 @@ def test_render_soup_frame_sizes_cover_every_sort_path(soup_pair, size):
     _compare_frames(rgba, ref_rgba, ids, ref_ids, 4, 1e-5)
 
 
+@pytest.mark.parametrize("size,grid", [((70, 45), 8), ((131, 77), 1), ((97, 65), 4)])
+def test_render_soup_frames_of_every_sample_grid_against_the_oracle(soup_pair, size, grid):
+    """1, 16 and 64 samples a pixel at frame sizes that fill no tile: the resolve kernel's wave holds a
+    quarter of a pixel's samples, four pixels or 256 of them, and must put each where the oracle does."""
+    g, o = soup_pair
+    W, H = size
+    ref_rgba, ref_ids, _ = o.render(W, H, grid, reflect_depth=1, diffuse_depth=1, want_hit_ids=True)
+    rgba, ids = g.render(render_params(W, H, grid, reflect_depth=1, diffuse_depth=1), want_hit_ids=True)
+    _compare_frames(rgba, ref_rgba, ids, ref_ids, grid * grid, 1e-5)
+    part = np.zeros_like(rgba)
+    for r in range(2):
+        part |= g.render(render_params(W, H, grid, reflect_depth=1, diffuse_depth=1, shard_index=r, shard_count=2))
+    assert np.array_equal(part, rgba)
+
+
 @pytest.mark.parametrize("which", ["teapot", "soup"])
 def test_device_built_tree_gives_the_same_answers(which, ctx, oracle, default_objects, soup64k):
     """RT_BUILD_DEVICE builds the trees on the GPU (Morton order, fixed fan-out). The structure
