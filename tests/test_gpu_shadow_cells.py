@@ -210,6 +210,35 @@ def test_cells_with_occluders_at_the_depth_of_the_rays(ctx, oracle, monkeypatch,
     _frames(ctx, oracle, objs, monkeypatch, [(160, 90, 2), (96, 54, 4)], sun=sun)
 
 
+def test_cells_equal_the_tree_walk_on_random_scenes(ctx, monkeypatch):
+    """The scenes of tools/cells_fuzz.py (needles, triangles edge-on to the sun, flat layers at equal
+    depth, sizes from 0.05 to 1 unit, suns 30 to 100,000 units away on every side): the frame by cells must
+    be the frame by tree walk. profiles/r02_cells_fuzz.txt keeps a run of 300 such scenes."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "cells_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "cells_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    taken = 0
+    for seed in range(5000, 5008):
+        rng = np.random.default_rng(seed)
+        sun = fuzz.sun_of(rng)
+        g = Scene(ctx, fuzz.scene_of(rng, sun))
+        try:
+            p = render_params(640, 360, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+            monkeypatch.setenv("RAYS_HIP_SHADOW", "cells")
+            rgba, st = _render_stats(g, p)
+            taken += _took_cells(st)
+            monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+            rgba_walk, _ = _render_stats(g, p)
+            assert np.array_equal(rgba, rgba_walk), f"seed {seed}: {(rgba != rgba_walk).any(axis=2).sum()} pixels differ"
+        finally:
+            g.close()
+    assert taken >= 6, "the scenes were meant for the light-space cells"
+
+
 @pytest.mark.parametrize("shards", [2, 5])
 def test_cells_in_sharded_frames(soup200k, monkeypatch, shards):
     """A shard's rays are a fraction of the frame's, spread over all the light-space cells; the lists

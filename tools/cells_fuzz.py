@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the light-space shadow search against the tree walk: soups of assorted
+triangle sizes and shapes (needles, large triangles, triangles turned edge-on to the sun, flat layers
+at equal depth) under suns near and far on every side; the two shadow paths must give the same frame.
+usage: python tools/cells_fuzz.py [rounds] [first seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401
+
+from raytracing_amd import Context, Scene, render_params, scenes  # noqa: E402
+
+
+def as_object(v):
+    n = len(v)
+    nrm = np.nan_to_num(scenes.calculate_normals(v[:, 0], v[:, 1], v[:, 2]), nan=0.0, posinf=0.0, neginf=0.0)
+    col = np.tile(np.array([[0.8, 0.6, 0.4]], dtype=np.float32), (n, 1))
+    return {"verts": v.reshape(-1, 3), "tris": np.arange(3 * n, dtype=np.uint32).reshape(n, 3),
+            "tri_data": np.concatenate([nrm, col], axis=1).astype(np.float32), "material": (0.3, 0.0, 1.0)}
+
+
+def scene_of(rng, sun):
+    n = int(rng.choice([40_000, 80_000, 160_000]))
+    n -= n % 8
+    c = np.stack([rng.uniform(-10, 10, n), rng.uniform(-6, 6, n), rng.uniform(5, 25, n)], axis=1)
+    # in Morton order of the centres, as the benchmark soups are: a leaf's eight triangles lie together
+    lo, hi = np.array([-10.0, -6.0, 5.0]), np.array([10.0, 6.0, 25.0])
+    c = c[np.argsort(scenes._morton30(c, lo, hi), kind="stable")]
+    size = rng.choice([0.05, 0.1, 0.3, 1.0], size=(n, 1), p=[0.35, 0.45, 0.17, 0.03])
+    e1 = rng.uniform(-1, 1, (n, 3)) * size
+    e2 = rng.uniform(-1, 1, (n, 3)) * size
+    kind = rng.integers(0, 100, n)
+    kind = np.where(kind < 5, 0, np.where(kind < 6, 1, np.where(kind < 16, 2, 3)))   # 5 % needles, 1 % edge-on, 10 % flat
+    needle = kind == 0                      # second edge nearly along the first
+    e2[needle] = e1[needle] * rng.uniform(0.2, 1.0, (needle.sum(), 1)) + rng.normal(size=(needle.sum(), 3)) * 1e-3
+    edge_on = kind == 1                     # first edge along the direction to the sun, or nearly
+    to_sun = np.asarray(sun, dtype=np.float64) - c
+    to_sun /= np.linalg.norm(to_sun, axis=1, keepdims=True)
+    e1[edge_on] = to_sun[edge_on] * size[edge_on] * rng.uniform(0.5, 2.0, (edge_on.sum(), 1)) + \
+        rng.normal(size=(edge_on.sum(), 3)) * rng.choice([0.0, 1e-6, 1e-4, 1e-2], size=(edge_on.sum(), 1))
+    flat = kind == 2                        # layers across the light's dominant axis at a handful of depths
+    ax = int(np.argmax(np.abs(np.asarray(sun) - np.array([0.0, 0.0, 15.0]))))
+    e1[flat, ax] = 0.0
+    e2[flat, ax] = 0.0
+    levels = np.array([8.0, 8.0 + 1e-5, 12.0, 12.001, 20.0]) if ax == 2 else np.array([-2.0, -2.0 + 1e-5, 0.0, 1e-3, 3.0])
+    c[flat, ax] = rng.choice(levels, size=flat.sum())
+    a = c - (e1 + e2) / 3.0
+    v = np.stack([a, a + e1, a + e2], axis=1).astype(np.float32)
+    v[..., 2] = np.maximum(v[..., 2], 0.5)
+    return [as_object(v)]
+
+
+def sun_of(rng):
+    far = rng.choice([30.0, 100.0, 1.0e3, 1.0e5])
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d)
+    return tuple(float(x) for x in (np.array([0.0, 0.0, 15.0]) + d * far))
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = Context(0)
+    took = bad = 0
+    for k in range(rounds):
+        rng = np.random.default_rng(seed0 + k)
+        sun = sun_of(rng)
+        g = Scene(ctx, scene_of(rng, sun))
+        p = render_params(640, 360, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+        frame = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda")
+        os.environ["RAYS_HIP_SHADOW"] = "cells"
+        st = g.render_device_stats(p, frame.data_ptr())
+        a = g.render(p)
+        os.environ["RAYS_HIP_SHADOW"] = "walk"
+        b = g.render(p)
+        del os.environ["RAYS_HIP_SHADOW"]
+        diff = int((a != b).any(axis=2).sum())
+        took += int(st["shadow_by_cells"])
+        bad += diff != 0
+        print(f"seed {seed0 + k}: sun ({sun[0]:.1f}, {sun[1]:.1f}, {sun[2]:.1f})  tris {g.num_tris}  by cells {st['shadow_by_cells']}  "
+              f"longest list {st['shadow_list_longest']}  shadow rays {st['rays'] - st['primary_rays']}  pixels that differ {diff}", flush=True)
+        g.close()
+    ctx.close()
+    print(f"{rounds} scenes, {took} by cells, {bad} with differences")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
