@@ -2,6 +2,8 @@
 """Randomised cross-check of the light-space shadow search against the tree walk: soups of assorted
 triangle sizes and shapes (needles, large triangles, triangles turned edge-on to the sun, flat layers
 at equal depth) under suns near and far on every side; the two shadow paths must give the same frame.
+The camera rays are cross-checked on the way: by projection (whenever the scene allows it) against the
+tree walk, hit id by hit id.
 usage: python tools/cells_fuzz.py [rounds] [first seed]"""
 import os
 import sys
@@ -71,17 +73,22 @@ def main():
         g = Scene(ctx, scene_of(rng, sun))
         p = render_params(640, 360, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
         frame = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda")
+        os.environ["RAYS_HIP_RASTER_RATIO"] = "1e9"   # projection even where the tree walk would be cheaper
         os.environ["RAYS_HIP_SHADOW"] = "cells"
         st = g.render_device_stats(p, frame.data_ptr())
-        a = g.render(p)
+        a, ids = g.render(p, want_hit_ids=True)
         os.environ["RAYS_HIP_SHADOW"] = "walk"
         b = g.render(p)
-        del os.environ["RAYS_HIP_SHADOW"]
+        os.environ["RAYS_HIP_RASTER"] = "0"
+        c, ids_walk = g.render(p, want_hit_ids=True)
+        del os.environ["RAYS_HIP_SHADOW"], os.environ["RAYS_HIP_RASTER"]
         diff = int((a != b).any(axis=2).sum())
+        id_diff = int((ids != ids_walk).sum())
         took += int(st["shadow_by_cells"])
-        bad += diff != 0
+        bad += diff != 0 or id_diff != 0 or not np.array_equal(b, c)
         print(f"seed {seed0 + k}: sun ({sun[0]:.1f}, {sun[1]:.1f}, {sun[2]:.1f})  tris {g.num_tris}  by cells {st['shadow_by_cells']}  "
-              f"longest list {st['shadow_list_longest']}  shadow rays {st['rays'] - st['primary_rays']}  pixels that differ {diff}", flush=True)
+              f"longest list {st['shadow_list_longest']}  shadow rays {st['rays'] - st['primary_rays']}  pixels that differ {diff}  "
+              f"camera rays by projection {st['camera_by_projection']}  hit ids that differ {id_diff}", flush=True)
         g.close()
     ctx.close()
     print(f"{rounds} scenes, {took} by cells, {bad} with differences")
