@@ -213,7 +213,8 @@ def test_cells_with_occluders_at_the_depth_of_the_rays(ctx, oracle, monkeypatch,
 def test_cells_equal_the_tree_walk_on_random_scenes(ctx, monkeypatch):
     """The scenes of tools/cells_fuzz.py (needles, triangles edge-on to the sun, flat layers at equal
     depth, sizes from 0.05 to 1 unit, suns 30 to 100,000 units away on every side): the frame by cells must
-    be the frame by tree walk. profiles/r02_cells_fuzz.txt keeps a run of 300 such scenes."""
+    be the frame by tree walk. The tool itself runs as many scenes as it is asked for and also checks the
+    camera rays by projection against the tree walk."""
     import importlib.util
     import os
 
