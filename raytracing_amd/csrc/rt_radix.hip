@@ -5,6 +5,7 @@
 //   k_radix_hist     one wave per block of RT_RADIX_BLOCK keys: digit histogram of the valid keys
 //   k_radix_groups   sums of the histograms over groups of 256 blocks
 //   k_radix_bases    where every (digit, group) starts: digits in order, groups in order within a digit
+//                    (folded into k_radix_offsets while the groups are few)
 //   k_radix_offsets  where every (digit, block) starts
 //   k_radix_scatter  one wave per block goes through its keys in order, 64 at a time: the lanes that
 //                    share a digit find each other with eight ballots (one per bit), take consecutive
@@ -124,12 +125,41 @@ __global__ __launch_bounds__(256) void k_radix_bases(const uint32_t* __restrict_
     if (d == 0 && set_count) *n_valid = all;
 }
 
-// offsets[block][d] = the place where digit d of that block starts.
+// offsets[block][d] = the place where digit d of that block starts. OWN_BASES: the workgroup works its
+// group's bases out of `groups` itself (what k_radix_bases does, once per group instead of once: a few
+// hundred reads a thread while there are few groups, and one launch less per pass); workgroup 0 then
+// leaves the number of keys in *n_valid if set_count.
+#define RT_RADIX_OWN_BASES_GROUPS 128u   // most groups for which the offsets' workgroups do so
+template <bool OWN_BASES>
 __global__ __launch_bounds__(256) void k_radix_offsets(const uint32_t* __restrict__ hist, uint32_t n_blocks,
-                                                       const uint32_t* __restrict__ bases, uint32_t* __restrict__ offsets) {
+                                                       const uint32_t* __restrict__ bases, uint32_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ groups, uint32_t n_groups,
+                                                       uint32_t* __restrict__ n_valid, bool set_count) {
     const uint32_t d = threadIdx.x, g = blockIdx.x;
     const uint32_t b0 = g * RT_RADIX_GROUP, b1 = min(n_blocks, b0 + RT_RADIX_GROUP);
-    uint32_t run = bases[(size_t)g * 256u + d];
+    uint32_t run;
+    if (OWN_BASES) {
+        __shared__ uint32_t total[256];
+        uint32_t before = 0, sum = 0;   // this digit in the groups before this one, and in all of them
+#pragma unroll 16
+        for (uint32_t k = 0; k < n_groups; ++k) {
+            const uint32_t v = groups[(size_t)k * 256u + d];
+            before += k < g ? v : 0u;
+            sum += v;
+        }
+        total[d] = sum;
+        __syncthreads();
+        uint32_t lower = 0, all = 0;    // the digits below this one, and all keys
+        for (uint32_t k = 0; k < 256u; ++k) {
+            const uint32_t v = total[k];
+            lower += k < d ? v : 0u;
+            all += v;
+        }
+        run = lower + before;
+        if (g == 0 && d == 0 && set_count) *n_valid = all;
+    } else {
+        run = bases[(size_t)g * 256u + d];
+    }
 #pragma unroll 16
     for (uint32_t b = b0; b < b1; ++b) {
         offsets[(size_t)b * 256u + d] = run;
@@ -245,8 +275,14 @@ hipError_t radix_sort_valid(void* work, const uint32_t* keys_in, uint32_t* keys_
             hipLaunchKernelGGL(k_radix_hist<false>, dim3(p.n_blocks), dim3(64), 0, s, src_k, (uint32_t)n, d_n_valid, shift, hist);
         }
         hipLaunchKernelGGL(k_radix_groups, dim3(p.n_groups), dim3(256), 0, s, hist, p.n_blocks, groups);
-        hipLaunchKernelGGL(k_radix_bases, dim3(1), dim3(256), 0, s, groups, p.n_groups, bases, d_n_valid, pass == 0);
-        hipLaunchKernelGGL(k_radix_offsets, dim3(p.n_groups), dim3(256), 0, s, hist, p.n_blocks, bases, offsets);
+        if (p.n_groups <= RT_RADIX_OWN_BASES_GROUPS) {
+            hipLaunchKernelGGL(k_radix_offsets<true>, dim3(p.n_groups), dim3(256), 0, s, hist, p.n_blocks, bases, offsets, groups,
+                               p.n_groups, d_n_valid, pass == 0);
+        } else {
+            hipLaunchKernelGGL(k_radix_bases, dim3(1), dim3(256), 0, s, groups, p.n_groups, bases, d_n_valid, pass == 0);
+            hipLaunchKernelGGL(k_radix_offsets<false>, dim3(p.n_groups), dim3(256), 0, s, hist, p.n_blocks, bases, offsets, groups,
+                               p.n_groups, d_n_valid, false);
+        }
         if (pass == 0) {
             hipLaunchKernelGGL(k_radix_scatter<true>, dim3(p.n_blocks), dim3(64), 0, s, src_k, src_v, (uint32_t)n, d_n_valid,
                                shift, offsets, dst_k, dst_v);

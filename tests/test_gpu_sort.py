@@ -29,3 +29,12 @@ def test_own_sort_equals_the_library_sort(shim, n, key_bits, invalid):
     for clustered in (0, 1):
         rc = shim.radix_check(n, key_bits, 7 * n + key_bits + clustered, invalid, clustered)
         assert rc == 0, f"n={n} key_bits={key_bits} invalid={invalid}/256 clustered={clustered}: differs at {rc - 1}"
+
+
+@pytest.mark.parametrize("key_bits,invalid", [(16, 138), (24, 30)])
+def test_own_sort_with_more_groups_than_the_offsets_kernel_folds(shim, key_bits, invalid):
+    """70 M keys are 134 groups of 256 blocks: beyond 128 groups the groups' bases come from a kernel of
+    their own instead of being worked out by every workgroup of the offsets kernel."""
+    n = 70_000_000
+    rc = shim.radix_check(n, key_bits, 7 * n + key_bits, invalid, 0)
+    assert rc == 0, f"n={n} key_bits={key_bits} invalid={invalid}/256: differs at {rc - 1}"
