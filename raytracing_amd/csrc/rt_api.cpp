@@ -397,8 +397,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // Shadow rays by light-space cells when the scene's triangles spread thinly enough over the
     // light-space grid of the sort (decided on the device, from the lists' lengths; the tree walk
     // takes the launch otherwise). Not worth the lists for small scenes, nor for scenes whose
-    // lists are bound to be long: about 4 n_tris / cells entries per cell. The lists depend on the
-    // scene and the sun only; they are built on a stream of their own beside the camera rays.
+    // lists are bound to be long: a triangle whose box has mean sides (a, b) across the light goes to
+    // about (1 + a / cell) (1 + b / cell) cells, cell = the scene's side / cells a side (with the
+    // cells a quarter of a triangle's size, as for ten million triangles in the shards of an 8K frame,
+    // that is fifteen lists per triangle, and building them only to find them too long costs a shard
+    // a quarter of its time). The lists depend on the scene and the sun only; they are built on a
+    // stream of their own beside the camera rays.
     bool cells = false;
     uint32_t lc_cap_shift = 8, lc_mean = 0;
     if (mode == 0 && own_sort) {
@@ -406,9 +410,20 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const size_t lc_cells = (size_t)1 << lp.key_bits;
         // RAYS_HIP_SHADOW=walk: never; =cells: whenever no list outgrows its room, however long they are on average.
         const bool force = env_is("RAYS_HIP_SHADOW", 'c');
+        // Longest average list the cells are taken for (RAYS_HIP_SHADOW_CELL_MEAN overrides): the work
+        // per ray grows with it, the tree walk's does not.
+        const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
+        const uint32_t mean_limit = me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
+        const double per_axis = (double)(1u << (lp.key_bits / 2u));
+        double lists_per_tri = 1.0;
+        for (int axis : {lp.a1, lp.a2}) {
+            const double cell = ((double)s->bounds_hi[axis] - s->bounds_lo[axis]) / per_axis;
+            lists_per_tri *= cell > 0.0 ? 1.0 + s->mean_tri_side[axis] / cell : 1.0;
+        }
+        const double mean_list = lists_per_tri * s->n_tris_total / (double)lc_cells;
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
                 s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
-                (force || (s->n_tris_total >= 32768 && (size_t)s->n_tris_total * 4 <= lc_cells * 256));
+                (force || (s->n_tris_total >= 32768 && mean_list <= (double)mean_limit));
         // Room per cell: 256 entries (24 bytes each; 403 MB at 2^16 cells), 1024 when forced.
         lc_cap_shift = force && lp.key_bits <= 16 ? 10u : 8u;
         if (cells) {
@@ -437,10 +452,6 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                 HIP_TRY(hipEventCreateWithFlags(&s->side_fork[set], hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&s->side_done[set], hipEventDisableTiming));
             }
-            // Longest average list the cells are taken for (RAYS_HIP_SHADOW_CELL_MEAN overrides): the work
-            // per ray grows with it, the tree walk's does not.
-            const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
-            const uint32_t mean_limit = me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
             lc_mean = force ? 0xFFFFFFFFu : mean_limit;
         }
     }
@@ -837,6 +848,18 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             s->raster_sum_dy += dy;
             s->raster_sum_area += (double)dx * dy;
         }
+    }
+    {
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (size_t i = 0; i < (size_t)s->n_tris_total; ++i) {
+            const uint32_t* t = &tris_all[3 * i];
+            const float *a = &verts_all[3 * (size_t)t[0]], *b = &verts_all[3 * (size_t)t[1]], *c = &verts_all[3 * (size_t)t[2]];
+            for (int k = 0; k < 3; ++k) {
+                const float side = std::max(a[k], std::max(b[k], c[k])) - std::min(a[k], std::min(b[k], c[k]));
+                if (std::isfinite(side)) sum[k] += side;
+            }
+        }
+        for (int k = 0; k < 3; ++k) s->mean_tri_side[k] = s->n_tris_total ? sum[k] / s->n_tris_total : 0.0;
     }
 
     // ---- trees: one per object, over its 8-wide triangles ----------------------------------

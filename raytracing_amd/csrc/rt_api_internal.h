@@ -131,6 +131,9 @@ struct rt_scene {
     bool raster_ok = false;
     float raster_dx = 0.0f, raster_dy = 0.0f;
     double raster_sum_dx = 0.0, raster_sum_dy = 0.0, raster_sum_area = 0.0;  // over all triangles
+    // Mean side of a triangle's bounding box along x, y, z: how many cells of the light-space grid a
+    // triangle's patch is likely to touch (the estimate that decides whether the lists are tried).
+    double mean_tri_side[3] = {0.0, 0.0, 0.0};
     uint32_t n_tris_total = 0;
     SceneView view{};
     std::vector<void*> device_ptrs;
