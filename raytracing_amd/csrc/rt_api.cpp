@@ -374,17 +374,19 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         raster = !env_is("RAYS_HIP_RASTER", 'a') || bx * by <= 16384.0f;   // a block no sample of which passes the half-planes costs ~25 instructions
         // Its work grows with the summed area of the triangles' boxes (every layer of depth is
         // tested), the tree walk's with the number of samples. Projection is taken while its
-        // estimate stays at or below 64 sample slots per sample of the frame; measured camera +
-        // shadow frames, projection against tree walk: 1 M triangles at 3840 x 2160 (estimate 29)
-        // 4.1 / 5.8 ms, at 960 x 540 (67) 1.27 / 1.40 ms; 3 M at 3840 x 2160 (87) 6.0 / 5.3 ms;
-        // 10 M (291) 13.2 / 5.2 ms.
+        // estimate stays at or below 160 sample slots per sample of the frame; measured camera
+        // phases, projection by screen tile against tree walk: 1 M triangles at 3840 x 2160
+        // (estimate 29) 0.82 / 3.13 ms, at 960 x 540 (69) 0.36 / 0.56, at 640 x 360 (104) 0.47 / 0.76;
+        // 2 M at 1920 x 1080 (83) 0.59 / 1.26; 3 M at 3840 x 2160 (92) 1.73 / 2.85; 5 M (152) 2.68 /
+        // 3.03. (The older form with atomic minima broke even near 64; 10 M triangles, estimate 291,
+        // took it 13.2 ms against the walk's 5.2.)
         const double sx = (double)(p->width * p->grid) * 0.5 / aspect / 8.0, sy = (double)(p->height * p->grid) * 0.5 / 8.0;
         // Blocks of 8 x 8 samples: a box of w samples takes about w / 8 + 0.7 blocks a side.
         const double blocks = sx * sy * s->raster_sum_area + 0.7 * sx * s->raster_sum_dx + 0.7 * sy * s->raster_sum_dy +
                               0.49 * (double)s->n_tris_total;
         const double ratio = blocks * 64.0 / ((double)p->width * p->height * spp);
         const char* lim_env = std::getenv("RAYS_HIP_RASTER_RATIO");
-        const double limit = lim_env ? std::atof(lim_env) : 64.0;
+        const double limit = lim_env ? std::atof(lim_env) : (env_is("RAYS_HIP_RASTER", 'a') ? 64.0 : 160.0);
         if (std::getenv("RAYS_HIP_VERBOSE"))
             std::fprintf(stderr, "rays_hip: projection would test %.1f sample slots per sample (limit %.1f)\n", ratio, limit);
         raster = raster && ratio <= limit;
