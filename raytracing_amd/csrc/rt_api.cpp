@@ -427,9 +427,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const double mean_list = lists_per_tri * s->n_tris_total / (double)lc_cells;
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
                 s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
-                (force || (s->n_tris_total >= 32768 && mean_list <= (double)mean_limit));
-        // Room per cell: 256 entries (24 bytes each; 403 MB at 2^16 cells), 1024 when forced.
-        lc_cap_shift = force && lp.key_bits <= 16 ? 10u : 8u;
+                (force || (s->n_tris_total >= 32768 && mean_list <= 1.4 * (double)mean_limit));   // the estimate runs 1.4 x high on the soups
+        // Room per cell: 512 entries at 2^16 cells (24 bytes each: 805 MB), 1024 when forced; 256 at 2^18.
+        lc_cap_shift = lp.key_bits <= 16 ? (force ? 10u : 9u) : 8u;
         if (cells) {
             if (w.lc_cells < lc_cells) {
                 if (w.lc_counts) (void)hipFree(w.lc_counts);
