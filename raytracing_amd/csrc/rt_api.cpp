@@ -192,7 +192,30 @@ int ensure_work(FrameWork& w, size_t n, hipStream_t stream) {
 
 // Projection from the sun across its dominant axis, scaled to the scene's bounds, and the number of
 // key bits to sort n shadow-ray candidates on.
-LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t n) {
+// Mean length the light-space lists are expected to have with 2^key_bits cells: a triangle whose box
+// has mean sides (a, b) across the light goes to about (1 + a / cell) (1 + b / cell) cells, cell = the
+// scene's side / cells a side. Runs about 1.4 x high on random soups.
+static double cells_mean_list(const rt_scene* s, const LightProj& lp, uint32_t key_bits) {
+    const double per_axis = (double)(1u << (key_bits / 2u));
+    double lists_per_tri = 1.0;
+    for (int axis : {lp.a1, lp.a2}) {
+        const double cell = ((double)s->bounds_hi[axis] - s->bounds_lo[axis]) / per_axis;
+        lists_per_tri *= cell > 0.0 ? 1.0 + s->mean_tri_side[axis] / cell : 1.0;
+    }
+    return lists_per_tri * s->n_tris_total / (double)((size_t)1 << key_bits);
+}
+// Longest mean list the cells are taken for (RAYS_HIP_SHADOW_CELL_MEAN overrides): the work per ray
+// grows with it, the tree walk's does not.
+static uint32_t cells_mean_limit() {
+    const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
+    return me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
+}
+
+// coarse: the frame's shadow rays may go by light-space cells; then 16 key bits are kept whenever the
+// lists come out short enough with them, however many rays there are (more rays per cell only mean
+// more waves per list, and every 8 bits more cost the sort a pass: 8K frame of a million triangles,
+// 16 against 18 bits: sort 1.0 / 1.5 ms, shadow rays 2.2 / 2.0 ms).
+LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t n, bool coarse = false) {
     LightProj lp{};
     // Only the leading bits of the interleaved key are kept and sorted: the sort is stable, so the
     // rays of one cell keep their screen order, which is coherent enough within a cell of a few
@@ -206,8 +229,8 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
         }();
         uint32_t kb = 16;
         while (kb < 32 && ((size_t)512 << kb) < n) kb += 2;
-        if (env_bits >= 2 && env_bits <= 32) kb = (uint32_t)env_bits & ~1u;
         lp.key_bits = kb;
+        if (env_bits >= 2 && env_bits <= 32) lp.key_bits = (uint32_t)env_bits & ~1u, coarse = false;
     }
     float c[3], dsun[3];
     for (int k = 0; k < 3; ++k) {
@@ -247,6 +270,7 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
     lp.vscale = (ok && v1 > v0) ? 65535.0f / (v1 - v0) : 0.0f;
     lp.uabs = ok ? std::max(std::fabs(u0), std::fabs(u1)) : 0.0f;
     lp.vabs = ok ? std::max(std::fabs(v0), std::fabs(v1)) : 0.0f;
+    if (coarse && lp.key_bits > 16 && cells_mean_list(s, lp, 16) <= 1.4 * (double)cells_mean_limit()) lp.key_bits = 16;
     return lp;
 }
 
@@ -410,21 +434,12 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     bool cells = false;
     uint32_t lc_cap_shift = 8, lc_mean = 0;
     if (mode == 0 && own_sort) {
-        const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots);
+        const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots, true);
         const size_t lc_cells = (size_t)1 << lp.key_bits;
         // RAYS_HIP_SHADOW=walk: never; =cells: whenever no list outgrows its room, however long they are on average.
         const bool force = env_is("RAYS_HIP_SHADOW", 'c');
-        // Longest average list the cells are taken for (RAYS_HIP_SHADOW_CELL_MEAN overrides): the work
-        // per ray grows with it, the tree walk's does not.
-        const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
-        const uint32_t mean_limit = me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
-        const double per_axis = (double)(1u << (lp.key_bits / 2u));
-        double lists_per_tri = 1.0;
-        for (int axis : {lp.a1, lp.a2}) {
-            const double cell = ((double)s->bounds_hi[axis] - s->bounds_lo[axis]) / per_axis;
-            lists_per_tri *= cell > 0.0 ? 1.0 + s->mean_tri_side[axis] / cell : 1.0;
-        }
-        const double mean_list = lists_per_tri * s->n_tris_total / (double)lc_cells;
+        const uint32_t mean_limit = cells_mean_limit();
+        const double mean_list = cells_mean_list(s, lp, lp.key_bits);
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
                 s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
                 (force || (s->n_tris_total >= 32768 && mean_list <= 1.4 * (double)mean_limit));   // the estimate runs 1.4 x high on the soups
@@ -462,7 +477,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // Starts the list building on the side stream, after what `ws` holds so far (the scene and the sun
     // are all the lists depend on).
     auto start_lists = [&]() -> int {
-        const LightProj lp = light_projection(s, p, (size_t)total_tiles * tile_slots);
+        const LightProj lp = light_projection(s, p, (size_t)total_tiles * tile_slots, true);
         // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
         HIP_TRY(hipEventRecord(s->side_fork[set], ws));
         HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
@@ -547,7 +562,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         dp.tile_first = first;
         dp.n_tiles = std::min(run_tiles, total_tiles - first);
         const size_t n_slots = (size_t)dp.n_tiles * tile_slots;
-        const LightProj lp = light_projection(s, p, n_slots);
+        const LightProj lp = light_projection(s, p, n_slots, cells);
         if (first == 0) HIP_TRY(mark(7));   // set-up and binning done: the camera rays' main kernel is next
         if (raster_by_tile) {
             HIP_TRY(rtk::raster_tiles(s->view, dp, lp, d_list, w.cam_table, w.bin_offsets, w.bin_list, w.bin_recs, w.samp,
