@@ -29,12 +29,18 @@ def _compare_hits(gpu, ref, max_mismatch_frac):
 
 @pytest.fixture(scope="module")
 def teapot_pair(ctx, oracle, default_objects):
-    return Scene(ctx, default_objects), oracle.OracleScene(default_objects)
+    g, o = Scene(ctx, default_objects), oracle.OracleScene(default_objects)
+    yield g, o
+    g.close()
+    o.close()
 
 
 @pytest.fixture(scope="module")
 def soup_pair(ctx, oracle, soup64k):
-    return Scene(ctx, soup64k), oracle.OracleScene(soup64k)
+    g, o = Scene(ctx, soup64k), oracle.OracleScene(soup64k)
+    yield g, o
+    g.close()
+    o.close()
 
 
 def test_scene_order_and_packing_match_oracle(teapot_pair):
