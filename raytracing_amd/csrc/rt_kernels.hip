@@ -2704,7 +2704,9 @@ __device__ __forceinline__ void sample_pos(uint32_t grid, uint32_t shift, uint32
 // `x`, computed with a rounded reciprocal, from the exact boundary by as much again unless it
 // lies far outside the tile. With RT_CLIP_SLACK = 1/16 column on either side the cut keeps every
 // passing column. An x that is NaN (gx == 0 with r == 0) cuts nothing.
+#ifndef RT_CLIP_SLACK
 #define RT_CLIP_SLACK 0.0625f
+#endif
 // The run [lo, hi] of columns is kept in floats and cut without a branch: a half-plane with gx > 0
 // raises lo to ceil(x - slack), one with gx < 0 lowers hi to floor(x + slack). `raise` is 0 for gx > 0
 // and -inf otherwise, `lower` 0 for gx < 0 and +inf otherwise (set once per triangle: see row_pens),

@@ -384,9 +384,9 @@ def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k, monkeypa
 
 
 def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, monkeypatch):
-    """Trailing triangles, triangles at or behind the camera plane, frames taller than wide and frames
-    with few samples for the scene's triangles take the tree walk; a triangle that covers a large part
-    of the frame does so only for the older form of the projection."""
+    """Trailing triangles, triangles at or behind the camera plane, triangles that would cover a large
+    part of the frame, frames taller than wide and frames with few samples for the scene's triangles
+    take the tree walk."""
     p = render_params(128, 72, 2, reflect_depth=1, diffuse_depth=1)
     g = Scene(ctx, soup64k)
     few = render_params(48, 27, 2, reflect_depth=1, diffuse_depth=1)
@@ -416,19 +416,7 @@ def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, mon
     rgba_walk, ids_walk = g.render(small, want_hit_ids=True)
     monkeypatch.delenv("RAYS_HIP_RASTER")
     assert np.array_equal(ids_walk, ids) and np.array_equal(rgba_walk, rgba)
-    # At 3840 x 2160 the triangle's box is the whole frame, half a million blocks: too many for the
-    # older form of the projection (one wave steps over a triangle's blocks), no obstacle by screen tile
-    # (the triangle joins every tile's list).
-    large = render_params(3840, 2160, 2, reflect_depth=1, diffuse_depth=1)
-    monkeypatch.setenv("RAYS_HIP_RASTER", "atomic")
-    assert _stats(g, large)["camera_by_projection"] == 0
-    monkeypatch.delenv("RAYS_HIP_RASTER")
-    assert _stats(g, large)["camera_by_projection"] == 1
-    rgba, ids = g.render(large, want_hit_ids=True)
-    monkeypatch.setenv("RAYS_HIP_RASTER", "0")
-    rgba_walk, ids_walk = g.render(large, want_hit_ids=True)
-    monkeypatch.delenv("RAYS_HIP_RASTER")
-    assert np.array_equal(ids_walk, ids) and np.array_equal(rgba_walk, rgba)
+    assert _stats(g, render_params(3840, 2160, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 0
     g.close()
     g = Scene(ctx, soup64k)
     assert _stats(g, render_params(72, 128, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 0
