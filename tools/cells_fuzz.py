@@ -4,7 +4,7 @@ triangle sizes and shapes (needles, large triangles, triangles turned edge-on to
 at equal depth) under suns near and far on every side; the two shadow paths must give the same frame.
 The camera rays are cross-checked on the way: by projection (whenever the scene allows it) against the
 tree walk, hit id by hit id.
-usage: [FUZZ_LARGE=1] python tools/cells_fuzz.py [rounds] [first seed]"""
+usage: [FUZZ_LARGE=1|medium] python tools/cells_fuzz.py [rounds] [first seed]"""
 import os
 import sys
 
@@ -34,7 +34,8 @@ def scene_of(rng, sun):
     size = rng.choice([0.05, 0.1, 0.3, 1.0], size=(n, 1), p=[0.35, 0.45, 0.17, 0.03])
     if os.environ.get("FUZZ_LARGE"):        # a few hundred triangles of 3 to 30 units among them
         large = rng.random(n) < 200.0 / n
-        size[large] = rng.choice([3.0, 10.0, 30.0], size=(int(large.sum()), 1))
+        sizes = [1.5, 3.0, 6.0] if os.environ["FUZZ_LARGE"] == "medium" else [3.0, 10.0, 30.0]
+        size[large] = rng.choice(sizes, size=(int(large.sum()), 1))
     e1 = rng.uniform(-1, 1, (n, 3)) * size
     e2 = rng.uniform(-1, 1, (n, 3)) * size
     kind = rng.integers(0, 100, n)
