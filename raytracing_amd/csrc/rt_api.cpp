@@ -387,8 +387,9 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // Camera rays by projection, unless the frame is taller than wide (aspect 0) or a triangle would
     // cover more than 16384 blocks of 8 x 8 samples. (The older form steps one wave over a triangle's
     // blocks; by screen tile a large box would cost little, but a randomised cross-check against the
-    // tree walk found one sample in 500 scenes of 3- to 30-unit triangles where a triangle with a box of
-    // 25,000 blocks was missed, so the limit, within which no difference has been seen, stays for both.)
+    // tree walk found one sample in 500 scenes of 3- to 30-unit triangles where a triangle was missed
+    // whose box was many times the frame (a vertex close to the camera plane), so the limit, within
+    // which no difference has been seen, stays for both.)
     bool raster = s->raster_ok && p->width >= p->height && p->width / p->height <= 4 &&
                   (uint64_t)p->width * p->grid < 65536u && (uint64_t)p->height * p->grid < 65536u &&  // 16-bit sample coordinates
                   !env_is("RAYS_HIP_RASTER", '0');
