@@ -103,8 +103,10 @@ typedef struct {
      * box_tests counts the light-space box tests of rays still unoccluded, tri_tests the pairs put
      * through the triangle test, and the shadow rays add nothing to node_visits and fetch_bytes.
      * shadow_list_*: the per-cell triangle lists of the frame (all entries, the longest list, the
-     * cells that have one); zero when the lists were not built.                                  */
-    uint64_t shadow_by_cells, shadow_list_entries, shadow_list_longest, shadow_list_cells;
+     * cells that have one); zero when the lists were not built. shadow_redone: rays whose occluder
+     * failed the box test of its leaf of eight (src/main.rs:192-200) and that the reference's own
+     * search then decided; normally zero.                                                         */
+    uint64_t shadow_by_cells, shadow_list_entries, shadow_list_longest, shadow_list_cells, shadow_redone;
 } rt_stats;
 
 /* Number of events rt_render_device_events records. */

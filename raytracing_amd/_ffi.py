@@ -75,6 +75,7 @@ class rt_stats(C.Structure):
         ("shadow_list_entries", C.c_uint64),
         ("shadow_list_longest", C.c_uint64),
         ("shadow_list_cells", C.c_uint64),
+        ("shadow_redone", C.c_uint64),
     ]
 
 

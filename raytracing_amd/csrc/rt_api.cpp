@@ -384,20 +384,19 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     if (!s->pipe_free[set]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_free[set], hipEventDisableTiming));
     // The buffers of this set are free once the resolve kernel of the frame that used them last is done.
     if (in_flight && s->pipe_free_set[set]) HIP_TRY(hipStreamWaitEvent(ws, s->pipe_free[set], 0));
-    // Camera rays by projection, unless the frame is taller than wide (aspect 0) or a triangle would
-    // cover more than 16384 blocks of 8 x 8 samples. (The older form steps one wave over a triangle's
-    // blocks; by screen tile a large box would cost little, but a randomised cross-check against the
-    // tree walk found one sample in 500 scenes of 3- to 30-unit triangles where a triangle was missed
-    // whose box was many times the frame (a vertex close to the camera plane), so the limit, within
-    // which no difference has been seen, stays for both.)
+    // Camera rays by projection, unless the frame is taller than wide (aspect 0). The older form
+    // (RAYS_HIP_RASTER=atomic) steps one wave over a triangle's blocks of 8 x 8 samples and is not taken
+    // when a triangle's box covers more than 16384 of them; by screen tile a large box costs little.
     bool raster = s->raster_ok && p->width >= p->height && p->width / p->height <= 4 &&
                   (uint64_t)p->width * p->grid < 65536u && (uint64_t)p->height * p->grid < 65536u &&  // 16-bit sample coordinates
                   !env_is("RAYS_HIP_RASTER", '0');
     if (raster) {
         const float aspect = (float)(p->width / p->height);
-        const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
-        const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
-        raster = bx * by <= 16384.0f;   // a block no sample of which passes the half-planes costs ~25 instructions
+        if (env_is("RAYS_HIP_RASTER", 'a')) {
+            const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
+            const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
+            raster = bx * by <= 16384.0f;   // a block no sample of which passes the half-planes costs ~25 instructions
+        }
         // Its work grows with the summed area of the triangles' boxes (every layer of depth is
         // tested), the tree walk's with the number of samples. Projection is taken while its
         // estimate stays at or below 160 sample slots per sample of the frame; measured camera
@@ -484,7 +483,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         HIP_TRY(hipEventRecord(s->side_fork[set], ws));
         HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
         HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, lc_mean,
-                                 w.lc_flags, s->side_stream[set]));
+                                 w.lc_flags, w.keys[0], env_is("RAYS_HIP_CELLS_REDO", 'a'), s->side_stream[set]));
         HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
         return RT_OK;
     };
@@ -589,7 +588,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         if (cells) {
             HIP_TRY(hipStreamWaitEvent(ws, s->side_done[set], 0));
             HIP_TRY(rtk::shadow_cells(s->view, dp, lp, (uint32_t)n_slots, w.keys[1], w.order, w.samp, w.state, d_stats,
-                                      w.n_valid, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, w.lc_flags, ws));
+                                      w.n_valid, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, w.lc_flags, w.keys[0], ws));   // the sort is done with its input keys
         }
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
                                w.order, w.samp, w.state, d_stats, ws, own_sort ? w.n_valid : nullptr,
@@ -804,7 +803,9 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
         ob.reflectivity = d.reflectivity;
         ob.roughness = d.roughness;
         ob.root = rtbvh::EMPTY;
-        for (uint32_t l = 0; l < n_packed / 8; ++l) leaf_first.push_back(tri_base + l * 8);
+        // bit 31: one of the last n_leaves % 8 leaves, which stay out of the packets of eight (src/opt.rs:64-72)
+        for (uint32_t l = 0; l < n_packed / 8; ++l)
+            leaf_first.push_back((tri_base + l * 8) | (l < ((n_packed / 8) & ~7u) ? 0u : 0x80000000u));
         for (uint32_t i = n_packed; i < d.n_tris; ++i)
             for (int k = 0; k < 3; ++k) {
                 const float* v = &verts_all[3 * (size_t)tris_all[3 * (size_t)(tri_base + i) + k]];
@@ -862,7 +863,8 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
                 s->raster_ok = false;
                 break;
             }
-            const float dx = (float)ex, dy = (float)ey;
+            // the kernels clip a box to the frame: |dx| <= aspect <= 4, |dy| <= 1
+            const float dx = (float)std::min(ex, 8.0), dy = (float)std::min(ey, 2.0);
             s->raster_dx = std::max(s->raster_dx, dx);
             s->raster_dy = std::max(s->raster_dy, dy);
             s->raster_sum_dx += dx;
@@ -1006,6 +1008,8 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     HIP_TRY(tmp.alloc((void**)&d_order, n_recs_total * 4));
     HIP_TRY(pool.alloc((void**)&d_tri9, (size_t)total_tris * 36));
     HIP_TRY(pool.alloc((void**)&d_leaf_bounds, leaf_first.size() * 24));
+    float4* d_leaf_gate = nullptr;
+    HIP_TRY(pool.alloc((void**)&d_leaf_gate, std::max<size_t>(leaf_first.size(), 1) * 32));
     HIP_TRY(pool.alloc((void**)&d_data, data_all.size() * 4));
     HIP_TRY(pool.alloc((void**)&d_rest, rest_verts.size() * 4));
     HIP_TRY(pool.alloc((void**)&d_recs, n_recs_total * 48 + 192));  // padded: a leaf is read as 192 B
@@ -1082,7 +1086,7 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     }
     HIP_TRY(hipMemcpy(d_objs, s->objects.data(), s->objects.size() * sizeof(DevObject), hipMemcpyHostToDevice));
     HIP_TRY(rtk::pack_tris(d_verts, d_tris, (uint32_t)total_tris, d_tri9, 0));
-    HIP_TRY(rtk::leaf_bounds(d_verts, d_tris, d_leaf_first, (uint32_t)leaf_first.size(), d_leaf_bounds, 0));
+    HIP_TRY(rtk::leaf_bounds(d_verts, d_tris, d_leaf_first, (uint32_t)leaf_first.size(), d_leaf_bounds, d_leaf_gate, 0));
     HIP_TRY(rtk::gather_records(d_tri9, d_order, (uint32_t)n_recs_total, d_recs, 0));
     HIP_TRY(rtk::quantize_nodes(d_nodes, (uint32_t)n_nodes_total, d_qnodes, 0));
     HIP_TRY(hipDeviceSynchronize());
@@ -1106,6 +1110,9 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     s->view.recs = d_recs;
     s->view.tri9 = d_tri9;
     s->view.leaf_bounds = d_leaf_bounds;
+    s->view.leaf_gate = d_leaf_gate;
+    s->view.leaves_uniform = 1u;
+    for (const DevObject& ob : s->objects) s->view.leaves_uniform = (s->view.leaves_uniform && ob.n_rest == 0) ? 1u : 0u;
     s->view.tri_data = d_data;
     s->view.rest_verts = d_rest;
     s->device_ptrs = pool.ptrs;
@@ -1276,12 +1283,13 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     int rc = render_common(s, p, d_rgba8, d_hit_ids, d_stats, 0, nullptr, &hp, &projected, &hb, &lists);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    uint32_t lf[4] = {0, 0, 0, 0};   // usable, entries, longest, cells with a list (k_lcell_check)
+    uint32_t lf[6] = {0, 0, 0, 0, 0, 0};   // usable, entries, longest, cells with a list (k_lcell_check), -, rays done over
     if (lists) HIP_TRY(hipMemcpy(lf, s->work.lc_flags, sizeof(lf), hipMemcpyDeviceToHost));
     stats->shadow_by_cells = lf[0];
     stats->shadow_list_entries = lf[1];
     stats->shadow_list_longest = lf[2];
     stats->shadow_list_cells = lf[3];
+    stats->shadow_redone = lf[5];
     DevStats h;
     HIP_TRY(hipMemcpy(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
     stats->rays = h.rays;

@@ -47,6 +47,10 @@ struct SceneView {
                                 //   (v0.x v0.y v0.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z id - -)
     const float* tri9;          // reference order: e1 xyz, e2 xyz, v0 xyz per triangle
     const float* leaf_bounds;   // reference order: min xyz, max xyz per 8-triangle leaf
+    const float4* leaf_gate;    // the same boxes as two float4 a leaf: (min xyz, w) (max xyz, 0), w = 1 for a leaf in a
+                                // packet of eight (PackedBoxes::intersect), 0 for one of an object's last
+                                // n_leaves % 8 (box_intersection_check): what ref_leaf_gate reads
+    uint32_t leaves_uniform;    // 1: no object has trailing triangles, so triangle id lies in leaf id / 8
     const float* tri_data;      // reference order: normal xyz, color rgb per triangle
     const float* rest_verts;    // a xyz, b xyz, c xyz of every trailing triangle
     float beam_limit;           // widest beam footprint worth a beam walk (scene extent / 128)

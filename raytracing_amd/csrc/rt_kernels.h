@@ -18,8 +18,10 @@ hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint
 hipError_t trace_closest_linear(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
                                 hipStream_t s);
 hipError_t pack_tris(const float* d_verts, const uint32_t* d_tris, uint32_t n, float* d_tri9, hipStream_t s);
+// d_leaf_first[l]: first triangle of leaf l; bit 31 set for an object's last n_leaves % 8 leaves.
+// d_leaf_bounds: 6 floats a leaf; d_leaf_gate: 2 float4 a leaf (SceneView::leaf_gate).
 hipError_t leaf_bounds(const float* d_verts, const uint32_t* d_tris, const uint32_t* d_leaf_first, uint32_t n_leaves,
-                       float* d_leaf_bounds, hipStream_t s);
+                       float* d_leaf_bounds, float4* d_leaf_gate, hipStream_t s);
 // The 64-byte form of the 4-wide nodes that the persistent per-lane walk reads (node i -> 4 float4 at 4 i).
 hipError_t quantize_nodes(const rtbvh::Node4* d_nodes, uint32_t n, float4* d_qnodes, hipStream_t s);
 hipError_t gather_records(const float* d_tri9, const uint32_t* d_order, uint32_t n, float4* d_recs, hipStream_t s);
@@ -60,16 +62,19 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
 // the per-cell triangle lists for the grid of lp's key: 2^key_bits cells with room for 2^cap_shift entries
 // each (d_counts: one word per cell; d_boxes, d_ids: cells << cap_shift entries and four more), and leaves
 // d_flags[0] = 1 when every list fits its room and the lists of the cells that have one average at most
-// max_mean entries; d_flags[1..3] = the lists' total, the longest, the cells with a list (d_flags: 8
-// words). shadow_cells then decides the first *d_n_valid sorted rays when d_flags[0] is set and does
-// nothing otherwise; wf_shadow with d_done_flag = d_flags does the reverse.
+// max_mean entries; d_flags[1..3] = the lists' total, the longest, the cells with a list (d_flags: 64
+// words; from word 16 on what shadow_cells needs at its end: the leaf boxes and d_redo). redo_all (tests): every ray the lists find
+// occluded is decided over again by the reference's own search. shadow_cells then decides the first *d_n_valid sorted rays when d_flags[0] is set and does
+// nothing otherwise; wf_shadow with d_done_flag = d_flags does the reverse. d_redo: room for n words
+// (the slots of the rays whose occluder fails the reference's leaf test, counted in d_flags[5]; a second
+// kernel of the same call runs the reference's own search for them).
 hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
                        uint32_t* d_counts, float4* d_boxes, uint32_t* d_ids, uint32_t cap_shift, uint32_t max_mean,
-                       uint32_t* d_flags, hipStream_t s);
+                       uint32_t* d_flags, uint32_t* d_redo, bool redo_all, hipStream_t s);
 hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
                         const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
                         DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float4* d_boxes,
-                        const uint32_t* d_ids, uint32_t cap_shift, const uint32_t* d_flags, hipStream_t s);
+                        const uint32_t* d_ids, uint32_t cap_shift, uint32_t* d_flags, uint32_t* d_redo, hipStream_t s);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
 // Diffuse and mirror bounces as a pipeline: one launch of wf_bounce per level of the tree of

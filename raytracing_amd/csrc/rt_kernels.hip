@@ -34,6 +34,39 @@ struct HitD {
 
 __device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
+// The reference's own gate in front of a triangle of the 8-wide path: trace_ray tests the triangles of
+// a leaf (eight consecutive triangles) only for rays that pass the slab test of the leaf's box --
+// PackedBoxes::intersect for the leaves that fill packets of eight (src/main.rs:103-111,
+// src/simd_accel.rs:342-377), box_intersection_check for an object's last n_leaves % 8 leaves
+// (src/main.rs:134-136). A triangle test that rounds badly (a needle whose determinant cancels) can
+// accept a ray that passes the leaf's box by a thousandth of its size, which the reference never
+// tests; the searches here reach triangles by other routes (a tree of their own boxes, projection,
+// light-space cells), so a hit they are about to accept is put through this gate first. The ray
+// length is +inf, as the shadow search passes it (src/main.rs:185); the nearest-hit search passes the
+// nearest distance of the moment (src/main.rs:98,127), which can only cull a leaf whose entry distance
+// lies beyond a hit already found -- a triangle in it that still computes a nearer t (its t rounded to
+// before its own box) while an earlier triangle lies in between is the one case left out.
+// `ob` is the triangle's object, `id` its global number (not a trailing triangle).
+// lo4, hi4: the leaf's entry of SceneView::leaf_gate (its box, and which of the two tests it takes).
+__device__ __forceinline__ bool ref_leaf_gate(float4 lo4, float4 hi4, rt_f3 o, rt_f3 inv) {
+    const rt_f3 lo = f3(lo4.x, lo4.y, lo4.z), hi = f3(hi4.x, hi4.y, hi4.z);
+    return lo4.w != 0.0f ? packed_box_hit(lo, hi, o, inv, RT_INF) : box_intersection_check(o, inv, lo, hi);
+}
+__device__ __forceinline__ bool ref_leaf_gate(const SceneView& sv, const DevObject& ob, uint32_t id, rt_f3 o, rt_f3 inv) {
+    const float4* lg = sv.leaf_gate + 2 * (size_t)(ob.leaf_base + ((id - ob.tri_base) >> 3));
+    return ref_leaf_gate(lg[0], lg[1], o, inv);
+}
+// The same for callers that do not know the triangle's object.
+__device__ __forceinline__ bool ref_leaf_gate(const SceneView& sv, uint32_t id, rt_f3 o, rt_f3 inv) {
+    if (sv.leaves_uniform) {
+        const float4* lg = sv.leaf_gate + 2 * (size_t)(id >> 3);
+        return ref_leaf_gate(lg[0], lg[1], o, inv);
+    }
+    uint32_t oi = 0;
+    while (oi + 1 < sv.n_objs && id >= sv.objs[oi].tri_base + sv.objs[oi].n_tris) ++oi;
+    return ref_leaf_gate(sv, sv.objs[oi], id, o, inv);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-lane traversal stack: RT_STACK_LDS entries in LDS (lane-interleaved, conflict-free
 // 8-byte accesses), the rest in private memory. An entry is (node reference, entry distance).
@@ -1494,11 +1527,13 @@ __global__ void k_pack_tris(const float* __restrict__ verts, const uint32_t* __r
 // leaf_first_tri[l] is the (global, sorted) index of the leaf's first triangle.
 __global__ void k_leaf_bounds(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
                               const uint32_t* __restrict__ leaf_first_tri, uint32_t n_leaves,
-                              float* __restrict__ leaf_bounds) {
+                              float* __restrict__ leaf_bounds, float4* __restrict__ leaf_gate) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n_leaves) return;
     rt_f3 mn = f3(RT_INF, RT_INF, RT_INF), mx = f3(-RT_INF, -RT_INF, -RT_INF);
-    const uint32_t t0 = leaf_first_tri[l];
+    // bit 31: one of its object's last n_leaves % 8 leaves, which the reference keeps out of its packets of eight
+    const uint32_t t0 = leaf_first_tri[l] & 0x7FFFFFFFu;
+    const bool leftover = (leaf_first_tri[l] >> 31) != 0u;
     for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t* t = tris + 3 * (size_t)(t0 + j);
         const rt_f3 a = ld3(verts + 3 * (size_t)t[0]), b = ld3(verts + 3 * (size_t)t[1]),
@@ -1511,6 +1546,8 @@ __global__ void k_leaf_bounds(const float* __restrict__ verts, const uint32_t* _
     float* o = leaf_bounds + 6 * (size_t)l;
     o[0] = mn.x; o[1] = mn.y; o[2] = mn.z;
     o[3] = mx.x; o[4] = mx.y; o[5] = mx.z;
+    leaf_gate[2 * (size_t)l] = make_float4(mn.x, mn.y, mn.z, leftover ? 0.0f : 1.0f);
+    leaf_gate[2 * (size_t)l + 1] = make_float4(mx.x, mx.y, mx.z, 0.0f);
 }
 
 // The compact form of the 4-wide nodes that node_step_q reads. One thread per node. The node's box
@@ -2074,6 +2111,16 @@ __global__ void k_camera_table(SceneView sv, DevRenderParams p, float* __restric
 #define RT_RASTER_SLOP 0.125f   // samples: rounding of the projected vertices (hardware reciprocal, float products)
 #endif
 #define RT_RASTER_QUEUE 128     // candidate samples a wave holds before it tests 64 of them
+#ifndef RT_GATE_RASTER
+#define RT_GATE_RASTER 1
+#endif
+#ifndef RT_GATE_CELLS
+#define RT_GATE_CELLS 1
+#endif
+#ifdef RT_DEBUG_RASTER
+// Debug build only: triangle id, sample column, sample row to report on.
+__device__ uint32_t g_dbg[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+#endif
 // True when the shard owns one of the tiles that the sample rectangle [u0, u1] x [w0, w1] touches
 // (tile (tx, ty) belongs to shard (tx + ty) % count). gs = log2(samples per pixel side).
 __device__ __forceinline__ bool shard_touches(const DevRenderParams& p, uint32_t gs, int u0, int u1, int w0, int w1) {
@@ -2328,6 +2375,8 @@ __global__ __launch_bounds__(64, 8) void k_raster(SceneView sv, DevRenderParams 
             if (STATS) st.box += 1, st.bytes += 16;
             if (!raster_object_box(sv, tab, L, gw, ow, su, sw)) return;
         }
+        // the reference tests the triangle only if the ray passes the box of its leaf
+        if (!ref_leaf_gate(sv, sv.objs[ow & 0x7FFFFFFFu], id, o, g_recip(d))) return;
         if (STATS) st.bytes += 8;
         const uint32_t x = su >> gs, y = sw >> gs;
         const uint32_t smp = sample_of(g, su & (g - 1u), sw & (g - 1u));
@@ -2511,6 +2560,12 @@ __global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_to
     // A triangle whose box spans many tiles (a large one, or one whose box is only bounded by its
     // leaf) is walked by the whole wave, one lane per tile, so that no lane holds the others up.
     const bool big = any && (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) > 8u;
+#ifdef RT_DEBUG_RASTER
+    if (valid && id == g_dbg[0])
+        printf("bin<%d> tri %u: box u %d..%d w %d..%d any %d big %d objword %x\n  gu %a %a %a\n  gv %a %a %a\n  gw %a %a %a grow %g vis %d\n",
+               (int)FILL, id, rt.u0, rt.u1, rt.w0, rt.w1, (int)any, (int)big, rt.objword, rt.rs.gu.x, rt.rs.gu.y, rt.rs.gu.z,
+               rt.rs.gv.x, rt.rs.gv.y, rt.rs.gv.z, rt.rs.gw.x, rt.rs.gw.y, rt.rs.gw.z, rt.rs.grow, (int)rt.rs.visible);
+#endif
     unsigned long long bigs = __ballot(big);
     while (bigs != 0ull) {
         const int l = __builtin_ctzll(bigs);
@@ -2529,9 +2584,18 @@ __global__ void k_raster_bin(SceneView sv, DevRenderParams p, uint32_t n_tris_to
             if (!raster_tile_owned(p, gs, txk, tyk)) continue;
             const int x0 = max(u0, (int)(txk * RT_RTILE)), x1 = min(u1, (int)(txk * RT_RTILE + RT_RTILE - 1u));
             const int y0 = max(w0, (int)(tyk * RT_RTILE)), y1 = min(w1, (int)(tyk * RT_RTILE + RT_RTILE - 1u));
+#ifdef RT_DEBUG_RASTER
+            if (bid == g_dbg[0] && txk == g_dbg[1] / RT_RTILE && tyk == g_dbg[2] / RT_RTILE)
+                printf("bin<%d> big walk tri %u tile (%u,%u) rect %d..%d x %d..%d outside %d\n", (int)FILL, bid, txk, tyk, x0, x1, y0, y1,
+                       (int)raster_rect_outside(rs, gr, x0, x1, y0, y1));
+#endif
             if (raster_rect_outside(rs, gr, x0, x1, y0, y1)) continue;
             const uint32_t t = tyk * ntx + txk;
             const uint32_t pos = atomicAdd(&counts[t], 1u);
+#ifdef RT_DEBUG_RASTER
+            if (bid == g_dbg[0] && txk == g_dbg[1] / RT_RTILE && tyk == g_dbg[2] / RT_RTILE)
+                printf("bin<%d> big walk tri %u tile %u pos %u offset %u capacity %u\n", (int)FILL, bid, t, pos, FILL ? offsets[t] : 0u, capacity);
+#endif
             if (FILL && offsets[t] + pos < capacity) list[offsets[t] + pos] = bid;
         }
     }
@@ -2680,6 +2744,7 @@ struct RasterTileLds {
     uint16_t samples[RT_RTILE_GROUP][64 * RT_RUN];   // per wave: the samples of up to 64 runs, packed: sample | slot << 10
     uint16_t segs[RT_RTILE_GROUP][64 * (RT_RTILE / RT_SEG)];   // per wave: row segments of the current 64 triangles: lane | segment << 6
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
+    float idx[RT_RTILE], idy[RT_RTILE];          // their reciprocals, as Ray.inv_dir holds them (src/main.rs:329)
 };
 // Orders a wave's own LDS writes before its later LDS reads (the hardware serves one wave's LDS
 // instructions in order; this keeps the compiler from moving them).
@@ -2784,10 +2849,20 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         return c;
     };
     Stretch cur = fetch(wv * RT_RTILE_TRIS);
+#ifdef RT_DEBUG_RASTER
+    const bool dbg_tile = g_dbg[0] != 0xFFFFFFFFu && rtx == g_dbg[1] / RT_RTILE && rty == g_dbg[2] / RT_RTILE;
+    const uint32_t dbg_zi = (g_dbg[2] % RT_RTILE) * RT_RTILE + g_dbg[1] % RT_RTILE;
+    if (dbg_tile && lane == 0) printf("tile (%u,%u) index %u: first %u n_list %u su0 %d sw0 %d\n", rtx, rty, rt_index, first, n_list, su0, sw0);
+#endif
 
     for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE; i += 64u * RT_RTILE_GROUP) lds.z[i] = RT_ZKEY_NONE;
-    if (threadIdx.x < RT_RTILE) lds.dx[threadIdx.x] = tab[min(su0 + (int)threadIdx.x, gw - 1)];
-    else if (threadIdx.x < 2u * RT_RTILE) lds.dy[threadIdx.x - RT_RTILE] = tab[gw + min(sw0 + (int)(threadIdx.x - RT_RTILE), gh - 1)];
+    if (threadIdx.x < RT_RTILE) {
+        const float c = tab[min(su0 + (int)threadIdx.x, gw - 1)];
+        lds.dx[threadIdx.x] = c, lds.idx[threadIdx.x] = 1.0f / c;
+    } else if (threadIdx.x < 2u * RT_RTILE) {
+        const float c = tab[gw + min(sw0 + (int)(threadIdx.x - RT_RTILE), gh - 1)];
+        lds.dy[threadIdx.x - RT_RTILE] = c, lds.idy[threadIdx.x - RT_RTILE] = 1.0f / c;
+    }
     __syncthreads();
 
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform: runs wait at queue[(q_head .. q_tail) % RT_RASTER_QUEUE]
@@ -2831,6 +2906,10 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             const rt_f3 d = f3(lds.dx[zi & (RT_RTILE - 1u)], lds.dy[zi / RT_RTILE], 1.0f);
             if (STATS) st.tri += 1;
             const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+#ifdef RT_DEBUG_RASTER
+            if (dbg_tile && id == g_dbg[0] && zi == dbg_zi)
+                printf("tile test tri %u zi %u slot %u: t %a u %a v %a failed %d d %a %a ow %x\n", id, zi, code >> 10, ev.t, ev.u, ev.v, (int)ev.failed, d.x, d.y, ow);
+#endif
             if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
             if (!(ow & 0x80000000u)) {
                 if (STATS) st.box += 1, st.bytes += 16;
@@ -2864,6 +2943,10 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             td[6] = cur.r4.z, td[7] = cur.r4.w, td[8] = cur.r5.x;
             td[9] = __uint_as_float(cur.id);
             td[10] = c.w;
+#ifdef RT_DEBUG_RASTER
+            if (dbg_tile && cur.id == g_dbg[0])
+                printf("tile setup tri %u base %u lane %u: box u %d..%d w %d..%d -> c %d..%d r %d..%d\n", cur.id, base, lane, u0, u1, w0, w1, c0, c1, r0, r1);
+#endif
         }
         if (base + RT_RTILE_TRIS * RT_RTILE_GROUP < n_list) cur = fetch(base + RT_RTILE_TRIS * RT_RTILE_GROUP);
         // The triangles' boxes differ in height (ten rows on average, up to the tile's 32), so a wave in
@@ -2920,6 +3003,11 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                     row_clip(__builtin_fmaf(ru, ku, off), raise_u, lower_u, flo, fhi);
                     row_clip(__builtin_fmaf(rv, kv, off), raise_v, lower_v, flo, fhi);
                     row_clip(__builtin_fmaf(rw, kw, off), raise_w, lower_w, flo, fhi);
+#ifdef RT_DEBUG_RASTER
+                    if (dbg_tile && __float_as_uint(lds.tri[wv][t][9]) == g_dbg[0] && (uint32_t)row == dbg_zi / RT_RTILE)
+                        printf("tile row %d tri slot %d seg %u (sr %d..%d sc %d..%d): xu %g xv %g xw %g -> flo %g fhi %g; ru %a rv %a rw %a gx %a %a %a\n", row, t, sg, sr0, sr1,
+                               sc0, sc1, __builtin_fmaf(ru, ku, off), __builtin_fmaf(rv, kv, off), __builtin_fmaf(rw, kw, off), flo, fhi, ru, rv, rw, q.gu.x, q.gv.x, q.gw.x);
+#endif
                     // a half-plane that does not depend on the column passes the whole row or none of it
                     const bool none = (q.gu.x == 0.0f && ru < 0.0f) || (q.gv.x == 0.0f && rv < 0.0f) || (q.gw.x == 0.0f && rw < 0.0f);
                     // lo and hi stay within the box's columns whenever the run is not empty
@@ -2934,6 +3022,10 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                         const uint32_t len = min((uint32_t)(hi - lo + 1), RT_RUN);
                         const uint32_t pos = q_tail + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
                         lds.queue[wv][pos % RT_RASTER_QUEUE] = ((uint32_t)row * RT_RTILE + (uint32_t)lo) | (len << 10) | ((uint32_t)t << 16);
+#ifdef RT_DEBUG_RASTER
+                        if (dbg_tile && __float_as_uint(lds.tri[wv][t][9]) == g_dbg[0] && (uint32_t)row == dbg_zi / RT_RTILE)
+                            printf("tile queue row %d lo %d len %u slot %d pos %u (head %u tail %u)\n", row, lo, len, t, pos, q_head, q_tail);
+#endif
                         lo += (int)RT_RUN;
                     }
                     q_tail += (uint32_t)__builtin_popcountll(pm);
@@ -2952,6 +3044,9 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     }
 
     __syncthreads();   // both waves' nearest hits are in
+#ifdef RT_DEBUG_RASTER
+    if (dbg_tile && lane == 0) printf("tile final z[%u] = %llx\n", dbg_zi, lds.z[dbg_zi]);
+#endif
     // The records of the tile's samples, in slot order: what k_wf_primary stores.
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
     // Four samples a lane at a time: their nearest hits are read and their triangles' normals asked for
@@ -2959,11 +3054,32 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     // (the normal's address comes out of the nearest-hit word: two dependent reads per sample).
     constexpr uint32_t U = RT_RECORD_ROUND;
     static_assert(RT_RTILE * RT_RTILE % (64u * RT_RTILE_GROUP * U) == 0, "the tile's samples are dealt out in rounds of U per lane");
+    // A sample's nearest hit over again, with every accepted triangle put through the reference's leaf
+    // gate (ref_leaf_gate): for the rare sample whose nearest hit does not pass it. The tile's list holds
+    // every triangle the exact test can accept at any of the tile's samples.
+    auto rescan = [&](uint32_t sl, uint32_t wl) -> unsigned long long {
+        const rt_f3 d = f3(lds.dx[sl], lds.dy[wl], 1.0f), inv = g_recip(d);
+        unsigned long long best = RT_ZKEY_NONE;
+        for (uint32_t i = 0; i < n_list; ++i) {
+            const uint32_t id = list[first + i];
+            const float4* r = recs + (size_t)RT_RREC * id;
+            const float4 r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+            const uint32_t ow = __float_as_uint(r2.w);
+            const rt_tri_eval ev = tri_intersect(f3(r3.x, r3.y, r3.z), f3(r3.w, r4.x, r4.y), f3(r4.z, r4.w, r5.x), o, d);
+            if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
+            if (!(ow & 0x80000000u) && !raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + sl, (uint32_t)sw0 + wl)) continue;
+            if (!ref_leaf_gate(sv, sv.objs[ow & 0x7FFFFFFFu], id, o, inv)) continue;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
+            best = key < best ? key : best;
+        }
+        return best;
+    };
     for (uint32_t k0 = threadIdx.x; k0 < RT_RTILE * RT_RTILE; k0 += 64u * RT_RTILE_GROUP * U) {
         uint32_t sul[U], swl[U];
         bool inside[U], hit_any[U];
         HitD hs[U];
         rt_f3 normal[U];
+        float4 leaf_lo[U], leaf_hi[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
             const uint32_t k = k0 + u * 64u * RT_RTILE_GROUP;
@@ -2987,6 +3103,24 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             hs[u].obj = 0;
             while (hs[u].obj + 1 < sv.n_objs && hs[u].tri >= sv.objs[hs[u].obj].tri_base + sv.objs[hs[u].obj].n_tris) ++hs[u].obj;
             normal[u] = ld3(sv.tri_data + 6 * (size_t)hs[u].tri);
+            // no object of a projected scene has trailing triangles: leaf l of the scene holds triangles 8 l .. 8 l + 7
+            const float4* lg = sv.leaf_gate + 2 * (size_t)(hs[u].tri >> 3);
+            leaf_lo[u] = lg[0], leaf_hi[u] = lg[1];
+        }
+        // The reference tests a triangle only for rays that pass the box of its leaf (ref_leaf_gate): the
+        // nearest hit is checked against it, and the few samples whose nearest hit fails are worked out again.
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const rt_f3 inv = f3(lds.idx[sul[u]], lds.idy[swl[u]], 1.0f);
+            if (RT_GATE_RASTER && hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv)) {
+                const unsigned long long key = rescan(sul[u], swl[u]);
+                hit_any[u] = key != RT_ZKEY_NONE;
+                hs[u].tri = hit_any[u] ? (uint32_t)key : 0u;
+                hs[u].t = hit_any[u] ? __uint_as_float((uint32_t)(key >> 32)) : 0.0f;
+                hs[u].obj = 0;
+                while (hs[u].obj + 1 < sv.n_objs && hs[u].tri >= sv.objs[hs[u].obj].tri_base + sv.objs[hs[u].obj].n_tris) ++hs[u].obj;
+                normal[u] = ld3(sv.tri_data + 6 * (size_t)hs[u].tri);
+            }
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
@@ -3231,8 +3365,16 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
 // at most max_mean entries: then the shadow rays go by cells, otherwise by tree walk. flags[1..3] =
 // the lists' total, the longest, the cells with a list; flags[4] counts the workgroups that are done
 // (the last one decides) and is zero again afterwards.
+// What k_shadow_cells needs only at its very end, kept beside the flags (from word 16 on) and read from
+// there: as kernel arguments these would sit in scalar registers through the kernel's loop, which has
+// none to spare.
+struct CellsTail {
+    const float4* leaf_gate;
+    uint32_t* redo;
+    uint32_t redo_all;   // test switch: every ray the lists found occluded goes to k_shadow_redo
+};
 __global__ __launch_bounds__(256) void k_lcell_check(const uint32_t* __restrict__ counts, uint32_t n, uint32_t cap,
-                                                     uint32_t max_mean, uint32_t* __restrict__ flags) {
+                                                     uint32_t max_mean, uint32_t* __restrict__ flags, CellsTail tail) {
     __shared__ uint32_t s_last;
     uint32_t total = 0, longest = 0, used = 0;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -3260,6 +3402,7 @@ __global__ __launch_bounds__(256) void k_lcell_check(const uint32_t* __restrict_
         const bool ok = m <= cap && (uint64_t)t <= (uint64_t)max_mean * max(u, 1u);
         flags[0] = ok ? 1u : 0u;
         flags[4] = 0u;
+        *reinterpret_cast<CellsTail*>(flags + 16) = tail;
     }
 }
 
@@ -3267,6 +3410,7 @@ struct ShadowCellsLds {
     float ray[6][64];       // origin and direction of the wave's rays
     alignas(512) uint32_t queue[128];   // ring of (triangle entry << 6 | ray's lane) waiting for the exact test
     uint32_t hit[2];        // rays the last batch of exact tests found occluded
+    uint32_t occluder[64];  // per ray: a triangle the exact test accepted
 };
 static_assert(sizeof(uint32_t[128]) == 512, "ring_append wraps the ring's byte offset with a mask of 0x1fc");
 
@@ -3304,7 +3448,7 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
                                                         const uint32_t* __restrict__ counts,
                                                         const float4* __restrict__ boxes,
                                                         const uint32_t* __restrict__ ids, uint32_t cap_shift,
-                                                        const uint32_t* __restrict__ flags) {
+                                                        uint32_t* __restrict__ flags) {
     __shared__ ShadowCellsLds lds;
     if (flags[0] == 0u) return;
     const uint32_t lane = threadIdx.x;
@@ -3327,6 +3471,7 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     lds.ray[0][lane] = o.x, lds.ray[1][lane] = o.y, lds.ray[2][lane] = o.z;
     lds.ray[3][lane] = d.x, lds.ray[4][lane] = d.y, lds.ray[5][lane] = d.z;
     if (lane < 2u) lds.hit[lane] = 0u;
+    lds.occluder[lane] = 0xFFFFFFFFu;   // none from the lists so far
     // The objects' boxes (src/main.rs:178-180), one bit per object, and their trailing triangles.
     uint32_t objmask = 0u;
     {
@@ -3371,7 +3516,9 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
             // src/main.rs:185-193: a t with a clear sign bit occludes
             h = !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t);
             if (STATS) st.tri += 1;
-            if (h) atomicOr(&lds.hit[rl >> 5], 1u << (rl & 31u));
+            // the ray's occluder is kept for the leaf gate at the end (any one of them, if several lanes
+            // write at once)
+            if (h) atomicOr(&lds.hit[rl >> 5], 1u << (rl & 31u)), lds.occluder[rl] = e >> 6;
         }
         head += m;
         if (__ballot(h) != 0ull) {
@@ -3439,10 +3586,77 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         }
     }
     if (tail != head) flush(tail - head);
-    if (act && !((alive >> lane) & 1ull)) state[slot] |= RT_ST_OCC;
+    wave_lds_sync();
+    // The reference tests a triangle only for rays that pass the box of its leaf (ref_leaf_gate;
+    // src/main.rs:192-200, 214-216). Every ray the lists found occluded puts the occluder it was
+    // found with through that test, here at the end where the loop's registers are free. A ray whose
+    // occluder fails (a needle-shaped triangle whose test rounds badly) has been taken out of the search
+    // too early: it goes to the queue of k_shadow_redo, which runs the reference's own search for it.
+    bool occ = act && !((alive >> lane) & 1ull);
+    const uint32_t tri = lds.occluder[lane];
+    if (RT_GATE_CELLS && occ && tri != 0xFFFFFFFFu) {
+        const rt_f3 ro = f3(lds.ray[0][lane], lds.ray[1][lane], lds.ray[2][lane]);
+        const rt_f3 rd = f3(lds.ray[3][lane], lds.ray[4][lane], lds.ray[5][lane]);
+        const CellsTail* ct = reinterpret_cast<const CellsTail*>(flags + 16);
+        if (ONE_OBJ) {
+            // one object: leaf l holds the triangles 8 l .. 8 l + 7
+            const float4* lg = ct->leaf_gate + 2 * (size_t)(tri >> 3);
+            occ = ref_leaf_gate(lg[0], lg[1], ro, g_recip(rd));
+        } else {
+            occ = ref_leaf_gate(sv, tri, ro, g_recip(rd));
+        }
+        occ = occ && ct->redo_all == 0u;
+        if (!occ) ct->redo[atomicAdd(&flags[5], 1u)] = slot;
+    }
+    if (occ) state[slot] |= RT_ST_OCC;
     if (STATS) {
         st.bytes = 0;
         flush_stats(st, stats);
+    }
+}
+
+// The reference's shadow search (src/main.rs:185-233) for the few rays k_shadow_cells could not
+// decide (flags[5] of them, their sample slots in `queue`): one wave per ray, the lanes share the
+// object's leaves out among themselves; per leaf the reference's box test, then its eight triangles.
+// Any occluder will do, so the order in which the leaves are taken does not matter.
+__global__ __launch_bounds__(64) void k_shadow_redo(SceneView sv, DevRenderParams p, const uint32_t* __restrict__ queue,
+                                                    const uint32_t* __restrict__ flags, const float4* __restrict__ samp,
+                                                    uint32_t* __restrict__ state) {
+    const uint32_t n = flags[5], lane = threadIdx.x;
+    const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const uint32_t slot = queue[q];
+        const float4 a = samp[slot];
+        const rt_f3 o = f3(a.x, a.y, a.z), d = g_normalize(sun - o), inv = g_recip(d);
+        bool found = false;
+        for (uint32_t oi = 0; oi < sv.n_objs && !found; ++oi) {
+            const DevObject& ob = sv.objs[oi];
+            if (!box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) continue;
+            const uint32_t n_leaves = ob.n_tris >> 3;
+            for (uint32_t l0 = 0; l0 < n_leaves && !found; l0 += 64u) {
+                const uint32_t leaf = l0 + lane;
+                bool h = false;
+                if (leaf < n_leaves && ref_leaf_gate(sv, ob, ob.tri_base + 8u * leaf, o, inv)) {
+                    for (uint32_t j = 0; j < 8u; ++j) {
+                        const float* t9 = sv.tri9 + 9 * (size_t)(ob.tri_base + 8u * leaf + j);
+                        const rt_tri_eval ev = tri_intersect(ld3(t9), ld3(t9 + 3), ld3(t9 + 6), o, d);
+                        h = h || (!ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t));
+                    }
+                }
+                found = __ballot(h) != 0ull;
+            }
+            for (uint32_t r0 = 0; r0 < ob.n_rest && !found; r0 += 64u) {
+                const uint32_t r = r0 + lane;
+                bool h = false;
+                if (r < ob.n_rest) {
+                    const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
+                    float t, u, v;
+                    h = triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, RT_INF, &t, &u, &v);
+                }
+                found = __ballot(h) != 0ull;
+            }
+        }
+        if (found && lane == 0u) state[slot] |= RT_ST_OCC;
     }
 }
 
@@ -3896,10 +4110,10 @@ hipError_t pack_tris(const float* d_verts, const uint32_t* d_tris, uint32_t n, f
 }
 
 hipError_t leaf_bounds(const float* d_verts, const uint32_t* d_tris, const uint32_t* d_leaf_first, uint32_t n_leaves,
-                       float* d_leaf_bounds, hipStream_t s) {
+                       float* d_leaf_bounds, float4* d_leaf_gate, hipStream_t s) {
     if (n_leaves == 0) return hipSuccess;
     hipLaunchKernelGGL(k_leaf_bounds, dim3(grid_for(n_leaves, 256)), dim3(256), 0, s, d_verts, d_tris, d_leaf_first,
-                       n_leaves, d_leaf_bounds);
+                       n_leaves, d_leaf_bounds, d_leaf_gate);
     return hipGetLastError();
 }
 
@@ -3974,6 +4188,14 @@ hipError_t raster_bin(const SceneView& sv, const DevRenderParams& p, uint32_t n_
                       float4* d_recs, bool fill, hipStream_t s) {
     if (n_tris_total == 0) return hipSuccess;
     const dim3 grid((n_tris_total + 255u) / 256u);
+#ifdef RT_DEBUG_RASTER
+    {
+        const char *a = std::getenv("RAYS_HIP_DBG_TRI"), *b = std::getenv("RAYS_HIP_DBG_SU"), *c = std::getenv("RAYS_HIP_DBG_SW");
+        const uint32_t h[4] = {a ? (uint32_t)std::atoll(a) : 0xFFFFFFFFu, b ? (uint32_t)std::atoll(b) : 0u, c ? (uint32_t)std::atoll(c) : 0u, 0u};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), h, sizeof(h));
+    }
+#endif
     if (!fill) {
         const uint32_t lines = (p.width + p.height) * p.grid;
         hipLaunchKernelGGL(k_camera_table, dim3((lines + 255) / 256), dim3(256), 0, s, sv, p, d_table);
@@ -4046,7 +4268,7 @@ static LightCells light_cells(const SceneView& sv, const LightProj& lp) {
 
 hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
                        uint32_t* d_counts, float4* d_boxes, uint32_t* d_ids, uint32_t cap_shift, uint32_t max_mean,
-                       uint32_t* d_flags, hipStream_t s) {
+                       uint32_t* d_flags, uint32_t* d_redo, bool redo_all, hipStream_t s) {
     if (lp.key_bits < 2 || lp.key_bits > 24 || (lp.key_bits & 1u) || sv.n_objs > RT_LCELL_MAX_OBJS ||
         n_tris_total >= (1u << RT_LCELL_ID_BITS) || lp.key_bits + cap_shift > 31u)
         return hipErrorInvalidValue;
@@ -4058,14 +4280,14 @@ hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const Ligh
     hipLaunchKernelGGL(k_lcell_bin, dim3(grid_for(n_tris_total, 256)), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts,
                        d_boxes, d_ids, cap_shift);
     hipLaunchKernelGGL(k_lcell_check, dim3(std::min(64u, grid_for(lc.n_cells, 256))), dim3(256), 0, s, d_counts, lc.n_cells,
-                       1u << cap_shift, max_mean, d_flags);
+                       1u << cap_shift, max_mean, d_flags, CellsTail{sv.leaf_gate, d_redo, redo_all ? 1u : 0u});
     return hipGetLastError();
 }
 
 hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
                         const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
                         DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float4* d_boxes,
-                        const uint32_t* d_ids, uint32_t cap_shift, const uint32_t* d_flags, hipStream_t s) {
+                        const uint32_t* d_ids, uint32_t cap_shift, uint32_t* d_flags, uint32_t* d_redo, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = xcd_grid(grid_for(n, 64));
 #define RT_SC_LAUNCH(ST, ONE)                                                                                          \
@@ -4079,6 +4301,8 @@ hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const Lig
         else RT_SC_LAUNCH(false, false);
     }
 #undef RT_SC_LAUNCH
+    // the rays whose occluder the reference would not have tested (normally none)
+    hipLaunchKernelGGL(k_shadow_redo, dim3(std::min(256u, grid_for(n, 64))), dim3(64), 0, s, sv, p, d_redo, d_flags, d_samp, d_state);
     return hipGetLastError();
 }
 

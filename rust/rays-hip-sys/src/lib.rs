@@ -88,6 +88,7 @@ pub struct rt_stats {
     pub shadow_list_entries: u64,
     pub shadow_list_longest: u64,
     pub shadow_list_cells: u64,
+    pub shadow_redone: u64,
 }
 
 extern "C" {

@@ -1,0 +1,121 @@
+"""The reference tests a triangle only for rays that pass the box of its leaf of eight (src/main.rs:103-111,
+192-200). Projection and the light-space cells reach triangles by other routes and put the hits they are
+about to accept through that test (ref_leaf_gate); these scenes hold triangles for which it decides."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import Scene, render_params
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 360
+
+
+def _fuzz(monkeypatch):
+    monkeypatch.setenv("FUZZ_LARGE", "1")   # a few hundred triangles of 3 to 30 units among the small ones
+    spec = importlib.util.spec_from_file_location(
+        "cells_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "cells_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    return fuzz
+
+
+def _scene(fuzz, seed):
+    rng = np.random.default_rng(seed)
+    sun = fuzz.sun_of(rng)
+    return fuzz.scene_of(rng, sun), sun
+
+
+def _stats(g, p):
+    import torch
+    frame = torch.zeros((p.height, p.width, 4), dtype=torch.uint8, device="cuda")
+    return g.render_device_stats(p, frame.data_ptr())
+
+
+def test_needle_whose_test_rounds_badly_is_held_back_by_its_leaf_box(ctx, oracle, monkeypatch):
+    """Seed 20094 of tools/cells_fuzz.py with FUZZ_LARGE: triangle 10754 is a needle 13 units long and
+    0.1 wide; its triangle test, rounded as the reference rounds it, accepts the camera ray of sample
+    column 27, row 584 at t = 4.4218 (u + v = 0.9999), in front of the triangle's own nearest vertex at
+    z = 4.4226, and the ray passes the box of the needle's leaf by 0.0014. The reference never tests the
+    needle for that ray and returns triangle 10830 behind it. Projection finds every triangle a sample's
+    ray can be accepted by, so it has to apply the leaf's box test itself; the whole frame's hit ids must be
+    the oracle's, with a 20-unit triangle in the scene whose box is nine frames wide."""
+    fuzz = _fuzz(monkeypatch)
+    objs, sun = _scene(fuzz, 20094)
+    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+    monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")   # projection whatever the work estimate says
+    monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+    g = Scene(ctx, objs)
+    o = oracle.OracleScene(objs)
+    try:
+        assert _stats(g, p)["camera_by_projection"] == 1
+        rgba, ids = g.render(p, want_hit_ids=True)
+        ref, ref_ids, _ = o.render(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun, want_hit_ids=True)
+        s = (292 * W + 13) * 4 + 3
+        assert ref_ids[s] == 10830 and ids[s] == 10830
+        assert np.array_equal(ids, ref_ids), f"{int((ids != ref_ids).sum())} hit ids differ"
+        assert np.abs(rgba.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+        # the older form of projection (nearest hits by atomic minima in device memory) applies the same test
+        monkeypatch.setenv("RAYS_HIP_RASTER", "atomic")
+        small = render_params(160, 90, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+        _, ids_atomic = g.render(small, want_hit_ids=True)
+        monkeypatch.setenv("RAYS_HIP_RASTER", "0")
+        _, ids_walk = g.render(small, want_hit_ids=True)
+        assert np.array_equal(ids_atomic, ids_walk)
+    finally:
+        g.close()
+        o.close()
+
+
+def test_ray_in_the_plane_of_a_large_triangle(ctx, oracle, monkeypatch):
+    """Seed 20333: triangle 43741 (18 units) has an edge along the direction to the sun, and the shadow ray
+    of pixel (207, 210) lies in its plane, two units outside the triangle's own box but inside the box of its
+    leaf. The determinant of the reference's test is rounding noise there, above the test's epsilon, and the
+    test accepts (t = 2.24, u = 0.38, v = 0.33): the reference calls the pixel shadowed. The light-space cells
+    give such a triangle the patch of its leaf's box and agree; a tree over the triangles' own boxes cannot
+    (its deviation is one pixel here and stays written down, not asserted away)."""
+    fuzz = _fuzz(monkeypatch)
+    objs, sun = _scene(fuzz, 20333)
+    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+    g = Scene(ctx, objs)
+    o = oracle.OracleScene(objs)
+    try:
+        ref, ref_ids, _ = o.render(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun, want_hit_ids=True)
+        monkeypatch.setenv("RAYS_HIP_SHADOW", "cells")
+        assert _stats(g, p)["shadow_by_cells"] == 1
+        rgba, ids = g.render(p, want_hit_ids=True)
+        assert np.array_equal(ids, ref_ids)
+        assert np.abs(rgba.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+        monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+        walk = g.render(p)
+        off = np.argwhere(np.abs(walk.astype(np.int16) - ref.astype(np.int16)).max(axis=2) > 1)
+        assert len(off) <= 1 and all((y, x) == (210, 207) for y, x in off)
+    finally:
+        g.close()
+        o.close()
+
+
+@pytest.mark.parametrize("seed", [20094, 5003])
+def test_rays_sent_back_to_the_reference_search(ctx, monkeypatch, seed):
+    """A ray whose occluder fails the leaf's box test goes to a second kernel that runs the reference's
+    own shadow search for it (every leaf's box, then its eight triangles). RAYS_HIP_CELLS_REDO=all sends
+    every ray the lists found occluded that way: the frame must not change."""
+    fuzz = _fuzz(monkeypatch)
+    objs, sun = _scene(fuzz, seed)
+    p = render_params(320, 180, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+    g = Scene(ctx, objs)
+    try:
+        monkeypatch.setenv("RAYS_HIP_SHADOW", "cells")
+        st = _stats(g, p)
+        assert st["shadow_by_cells"] == 1 and st["shadow_redone"] == 0
+        rgba = g.render(p)
+        monkeypatch.setenv("RAYS_HIP_CELLS_REDO", "all")
+        assert _stats(g, p)["shadow_redone"] > 1000
+        again = g.render(p)
+        assert np.array_equal(rgba, again), f"{int((rgba != again).any(axis=2).sum())} pixels differ"
+        assert (rgba != 0).any()
+    finally:
+        g.close()

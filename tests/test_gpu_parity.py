@@ -384,9 +384,9 @@ def test_projection_keeps_the_lower_id_on_equal_t(ctx, oracle, soup64k, monkeypa
 
 
 def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, monkeypatch):
-    """Trailing triangles, triangles at or behind the camera plane, triangles that would cover a large
-    part of the frame, frames taller than wide and frames with few samples for the scene's triangles
-    take the tree walk."""
+    """Trailing triangles, triangles at or behind the camera plane, frames taller than wide and frames
+    with few samples for the scene's triangles take the tree walk; so do, for the older form of
+    projection only, triangles that cover a large part of the frame."""
     p = render_params(128, 72, 2, reflect_depth=1, diffuse_depth=1)
     g = Scene(ctx, soup64k)
     few = render_params(48, 27, 2, reflect_depth=1, diffuse_depth=1)
@@ -416,7 +416,19 @@ def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, mon
     rgba_walk, ids_walk = g.render(small, want_hit_ids=True)
     monkeypatch.delenv("RAYS_HIP_RASTER")
     assert np.array_equal(ids_walk, ids) and np.array_equal(rgba_walk, rgba)
-    assert _stats(g, render_params(3840, 2160, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 0
+    # by screen tile a triangle that covers the frame is one list entry a tile; the older form, which steps
+    # over a triangle's blocks of 8 x 8 samples, leaves such a frame to the tree walk
+    large = render_params(3840, 2160, 2, reflect_depth=1, diffuse_depth=1)
+    assert _stats(g, large)["camera_by_projection"] == 1
+    monkeypatch.setenv("RAYS_HIP_RASTER", "atomic")
+    assert _stats(g, large)["camera_by_projection"] == 0
+    monkeypatch.delenv("RAYS_HIP_RASTER")
+    mid = render_params(960, 540, 2, reflect_depth=1, diffuse_depth=1)
+    rgba, ids = g.render(mid, want_hit_ids=True)
+    monkeypatch.setenv("RAYS_HIP_RASTER", "0")
+    rgba_walk, ids_walk = g.render(mid, want_hit_ids=True)
+    monkeypatch.delenv("RAYS_HIP_RASTER")
+    assert np.array_equal(ids_walk, ids) and np.array_equal(rgba_walk, rgba)
     g.close()
     g = Scene(ctx, soup64k)
     assert _stats(g, render_params(72, 128, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 0

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Randomised cross-check of the light-space shadow search against the tree walk: soups of assorted
-triangle sizes and shapes (needles, large triangles, triangles turned edge-on to the sun, flat layers
-at equal depth) under suns near and far on every side; the two shadow paths must give the same frame.
-The camera rays are cross-checked on the way: by projection (whenever the scene allows it) against the
-tree walk, hit id by hit id.
-usage: [FUZZ_LARGE=1|medium] python tools/cells_fuzz.py [rounds] [first seed]"""
+"""Randomised cross-check of the light-space shadow search and of the camera rays by projection: soups
+of assorted triangle sizes and shapes (needles, large triangles, triangles turned edge-on to the sun,
+flat layers at equal depth) under suns near and far on every side. Each scene is rendered three ways
+(projection + cells, projection + tree walk, tree walk for everything); where two of them differ, in a
+pixel or a hit id, the CPU oracle renders the frame and decides. A scene counts as bad when projection
+or the cells differ from the oracle; a tree walk that differs from the oracle (it reaches a triangle
+through the triangle's own box, the reference through the box of its leaf of eight, and a triangle test
+that rounds badly can tell the two apart) is reported by itself.
+usage: [FUZZ_LARGE=1|medium] [FUZZ_W=640 FUZZ_H=360] python tools/cells_fuzz.py [rounds] [first seed]"""
 import os
 import sys
 
@@ -14,6 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401
 
 from raytracing_amd import Context, Scene, render_params, scenes  # noqa: E402
+
+W, H = int(os.environ.get("FUZZ_W", "640")), int(os.environ.get("FUZZ_H", "360"))
 
 
 def as_object(v):
@@ -70,13 +75,14 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     ctx = Context(0)
-    took = bad = 0
+    took = bad = walk_off = projected = 0
     for k in range(rounds):
         rng = np.random.default_rng(seed0 + k)
         sun = sun_of(rng)
-        g = Scene(ctx, scene_of(rng, sun))
-        p = render_params(640, 360, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
-        frame = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda")
+        objs = scene_of(rng, sun)
+        g = Scene(ctx, objs)
+        p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
         os.environ["RAYS_HIP_RASTER_RATIO"] = "1e9"   # projection even where the tree walk would be cheaper
         os.environ["RAYS_HIP_SHADOW"] = "cells"
         st = g.render_device_stats(p, frame.data_ptr())
@@ -89,13 +95,28 @@ def main():
         diff = int((a != b).any(axis=2).sum())
         id_diff = int((ids != ids_walk).sum())
         took += int(st["shadow_by_cells"])
-        bad += diff != 0 or id_diff != 0 or not np.array_equal(b, c)
+        projected += int(st["camera_by_projection"])
+        verdict = ""
+        if diff != 0 or id_diff != 0 or not np.array_equal(b, c):
+            from oracle import oracle_ffi
+            o = oracle_ffi.OracleScene(objs)
+            ref, ref_ids, _ = o.render(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun, want_hit_ids=True)
+            o.close()
+            # a, ids: projection + cells; b: projection + walk; c, ids_walk: walk + walk
+            lsb = lambda x: int((np.abs(x.astype(np.int16) - ref.astype(np.int16)).max(axis=2) > 1).sum())  # noqa: E731
+            fast_off = int((ids != ref_ids).sum()) + lsb(a)
+            walks_off = int((ids_walk != ref_ids).sum()) + lsb(c)
+            bad += fast_off != 0
+            walk_off += walks_off != 0
+            verdict = (f"  ORACLE: projection + cells off in {int((ids != ref_ids).sum())} ids / {lsb(a)} pixels, projection + walk in "
+                       f"{lsb(b)} pixels, tree walk in {int((ids_walk != ref_ids).sum())} ids / {lsb(c)} pixels")
         print(f"seed {seed0 + k}: sun ({sun[0]:.1f}, {sun[1]:.1f}, {sun[2]:.1f})  tris {g.num_tris}  by cells {st['shadow_by_cells']}  "
               f"longest list {st['shadow_list_longest']}  shadow rays {st['rays'] - st['primary_rays']}  pixels that differ {diff}  "
-              f"camera rays by projection {st['camera_by_projection']}  hit ids that differ {id_diff}", flush=True)
+              f"camera rays by projection {st['camera_by_projection']}  hit ids that differ {id_diff}{verdict}", flush=True)
         g.close()
     ctx.close()
-    print(f"{rounds} scenes, {took} by cells, {bad} with differences")
+    print(f"{rounds} scenes at {W}x{H}, {took} by cells, {projected} by projection; {bad} where projection or cells differ from the oracle, "
+          f"{walk_off} where the tree walk does")
     return 1 if bad else 0
 
 
