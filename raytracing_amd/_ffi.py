@@ -128,6 +128,13 @@ def hip_lib():
     if _hip is None:
         if not os.path.exists(HIP_LIB):
             raise RaysError(-2, f"{HIP_LIB} not found: build it with `python -m raytracing_amd.build`")
+        # PyTorch wheels bundle a HIP runtime of their own. Loaded before this library it serves both;
+        # loaded after it the process holds two runtimes whose streams, events and pointers do not mix
+        # (the library then refuses its device entry points). So where torch is installed it goes first.
+        import importlib.util
+        import sys
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None and not os.environ.get("RAYS_HIP_NO_TORCH"):
+            import torch  # noqa: F401
         lib = C.CDLL(HIP_LIB, mode=C.RTLD_GLOBAL)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)

@@ -2,8 +2,10 @@
 // Host code; every piece of arithmetic that reaches a result runs in the kernels.
 
 #include <hip/hip_runtime.h>
+#include <link.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +37,61 @@ int rt_fail(int code, const char* fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+
+// A process can end up with two HIP runtimes: this library binds to the system's libamdhip64.so.7, and a
+// Python wheel of PyTorch brings a copy of its own under another path, which the loader maps as well when
+// it comes second (loaded first, its soname satisfies this library too and there is one runtime). Streams,
+// events and device pointers of one runtime mean nothing to the other, and handing them across ends in an
+// abort inside the runtime. So every entry point that takes such a handle from the caller first makes sure
+// the process holds one runtime, and refuses otherwise. The walk over the loaded objects is repeated only
+// when the loader's count of objects added (dlpi_adds) has changed since the last one.
+namespace {
+struct RuntimeScan {
+    unsigned long long adds = 0;
+    int copies = 0;
+    char first[256] = "", second[256] = "";
+};
+int scan_adds(struct dl_phdr_info* info, size_t, void* out) {
+    *static_cast<unsigned long long*>(out) = info->dlpi_adds;
+    return 1;   // the counter is the same in every object's record: stop at the first
+}
+int scan_objects(struct dl_phdr_info* info, size_t, void* out) {
+    RuntimeScan* sc = static_cast<RuntimeScan*>(out);
+    sc->adds = info->dlpi_adds;
+    const char* name = info->dlpi_name ? info->dlpi_name : "";
+    const char* base = std::strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (std::strncmp(base, "libamdhip64.so", 14) != 0) return 0;
+    if (sc->copies == 0) std::snprintf(sc->first, sizeof(sc->first), "%s", name);
+    else if (std::strcmp(sc->first, name) == 0) return 0;
+    else if (sc->copies == 1) std::snprintf(sc->second, sizeof(sc->second), "%s", name);
+    sc->copies += 1;
+    return 0;
+}
+std::mutex g_scan_mu;
+RuntimeScan g_scan;
+std::atomic<unsigned long long> g_scan_adds{~0ull};
+std::atomic<int> g_scan_copies{0};
+}  // namespace
+
+int rt_runtime_guard() {
+    unsigned long long adds = 0;
+    dl_iterate_phdr(scan_adds, &adds);
+    if (adds != g_scan_adds.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lock(g_scan_mu);
+        RuntimeScan sc;
+        dl_iterate_phdr(scan_objects, &sc);
+        g_scan = sc;
+        g_scan_copies.store(sc.copies, std::memory_order_release);
+        g_scan_adds.store(sc.adds, std::memory_order_release);
+    }
+    if (g_scan_copies.load(std::memory_order_acquire) <= 1) return RT_OK;
+    std::lock_guard<std::mutex> lock(g_scan_mu);
+    return rt_fail(RT_ERR_UNSUPPORTED,
+                   "two HIP runtimes in one process (%s and %s): their streams, events and pointers do not mix; load the "
+                   "other one first (import torch before this library) so that both bind to the same copy",
+                   g_scan.first, g_scan.second);
 }
 
 namespace {
@@ -674,6 +731,7 @@ const char* rt_version(void) { return "rays-hip 0.1 (gfx950)"; }
 int rt_ctx_create(const int* devices, int n, rt_ctx** out) {
     if (!out) return rt_fail(RT_ERR_INVALID, "out is null");
     *out = nullptr;
+    if (int g = rt_runtime_guard()) return g;
     if (!devices || n != 1) return rt_fail(RT_ERR_INVALID, "exactly one device per context (one process per GPU)");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -1167,6 +1225,7 @@ int rt_scene_packed(const rt_scene* s, uint32_t obj, float* tris9, float* leaf_b
 
 int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, void* stream) {
     if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (int g = rt_runtime_guard()) return g;
     if (n == 0) return RT_OK;
     if (!d_rays || !d_out) return rt_fail(RT_ERR_INVALID, "null buffer");
     if (n > (1ull << 31) * RT_BLOCK) return rt_fail(RT_ERR_INVALID, "too many rays in one call");
@@ -1181,6 +1240,7 @@ int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hi
 
 int rt_trace_any_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, uint8_t* d_occluded, void* stream) {
     if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (int g = rt_runtime_guard()) return g;
     if (n == 0) return RT_OK;
     if (!d_rays || !d_occluded) return rt_fail(RT_ERR_INVALID, "null buffer");
     if (n > (1ull << 31) * RT_BLOCK) return rt_fail(RT_ERR_INVALID, "too many rays in one call");
@@ -1252,6 +1312,7 @@ uint32_t rt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_index, u
 
 int rt_render_device(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, void* stream) {
     if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (int g = rt_runtime_guard()) return g;
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     return render_common(s, p, d_rgba8, d_hit_ids, nullptr, (hipStream_t)stream);
@@ -1260,6 +1321,7 @@ int rt_render_device(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, u
 int rt_render_device_events(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids, void* stream,
                             void* const* events, int n_events) {
     if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (int g = rt_runtime_guard()) return g;
     if (!events || n_events != RT_RENDER_EVENTS) return rt_fail(RT_ERR_INVALID, "need %d events", RT_RENDER_EVENTS);
     for (int k = 0; k < n_events; ++k)
         if (!events[k]) return rt_fail(RT_ERR_INVALID, "event %d is null", k);
@@ -1271,6 +1333,7 @@ int rt_render_device_events(rt_scene* s, const rt_render_params* p, uint8_t* d_r
 int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint32_t* d_hit_ids,
                            rt_stats* stats) {
     if (!s || !stats) return rt_fail(RT_ERR_INVALID, "null argument");
+    if (int g = rt_runtime_guard()) return g;
     std::lock_guard<std::mutex> lock(s->ctx->mu);
     HIP_TRY(hipSetDevice(s->ctx->device));
     DevPool tmp;
@@ -1368,6 +1431,7 @@ int rt_deinterleave_tiles_device(rt_ctx* ctx, const uint8_t* d_gathered, uint32_
                                  uint32_t height, uint32_t shard_count, uint8_t* d_rgba8, void* stream) {
     if (!ctx || !d_gathered || !d_rgba8) return rt_fail(RT_ERR_INVALID, "null argument");
     if (width == 0 || height == 0 || shard_count == 0) return rt_fail(RT_ERR_INVALID, "bad frame or shard count");
+    if (int g = rt_runtime_guard()) return g;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     TileMap* tm = nullptr;

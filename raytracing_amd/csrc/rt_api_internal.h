@@ -15,6 +15,10 @@
 
 // Records the message rt_last_error() returns on the calling thread; returns `code`.
 int rt_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// RT_OK while the process holds one HIP runtime; RT_ERR_UNSUPPORTED (with both paths in the message) once a
+// second libamdhip64 is mapped. Called first by every entry point that takes a device, a stream, an event or
+// a device pointer from the caller.
+int rt_runtime_guard();
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \

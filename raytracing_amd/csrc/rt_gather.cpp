@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "rt_api_internal.h"
 #include "rt_kernels.h"
@@ -37,6 +38,7 @@ struct Rccl {
 std::mutex g_rccl_mu;
 Rccl g_rccl;
 bool g_rccl_tried = false;
+std::string g_rccl_why;   // why the first attempt to bind RCCL failed
 
 template <class F>
 bool bind(void* h, const char* name, F* out) {
@@ -49,7 +51,7 @@ const Rccl* rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.handle) return &g_rccl;
     if (g_rccl_tried) {
-        rt_fail(RT_ERR_UNSUPPORTED, "RCCL is not available in this process");
+        rt_fail(RT_ERR_UNSUPPORTED, "RCCL is not available in this process: %s", g_rccl_why.c_str());   // the first attempt's reason
         return nullptr;
     }
     g_rccl_tried = true;
@@ -60,7 +62,9 @@ const Rccl* rccl() {
     for (const char* n : names)
         if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (!h) {
-        rt_fail(RT_ERR_UNSUPPORTED, "cannot load librccl.so: %s", dlerror());
+        const char* why = dlerror();
+        g_rccl_why = std::string("cannot load librccl.so: ") + (why ? why : "unknown reason");
+        rt_fail(RT_ERR_UNSUPPORTED, "%s", g_rccl_why.c_str());
         return nullptr;
     }
     Rccl r;
@@ -71,7 +75,9 @@ const Rccl* rccl() {
                     bind(h, "ncclGroupEnd", &r.GroupEnd) && bind(h, "ncclSend", &r.Send) && bind(h, "ncclRecv", &r.Recv) &&
                     bind(h, "ncclGetErrorString", &r.GetErrorString);
     if (!ok) {
-        rt_fail(RT_ERR_UNSUPPORTED, "librccl.so lacks a symbol this library needs");
+        dlclose(h);
+        g_rccl_why = "librccl.so lacks a symbol this library needs";
+        rt_fail(RT_ERR_UNSUPPORTED, "%s", g_rccl_why.c_str());
         return nullptr;
     }
     g_rccl = r;
@@ -137,6 +143,7 @@ int rt_gather_tiles_device(rt_ctx* ctx, void* nccl_comm, const uint8_t* d_slab, 
                            uint8_t* d_rgba8, void* stream) {
     if (!ctx || !nccl_comm || !d_slab) return rt_fail(RT_ERR_INVALID, "null argument");
     if (width == 0 || height == 0) return rt_fail(RT_ERR_INVALID, "frame size is zero");
+    if (int g = rt_runtime_guard()) return g;
     const Rccl* R = rccl();
     if (!R) return RT_ERR_UNSUPPORTED;
     ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);

@@ -50,6 +50,7 @@ int rt_noalloc_setup(rt_ctx* ctx) {
 extern "C" int rt_trace_closest_device_noalloc(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
                                                void* stream) {
     if (!s) return rt_fail(RT_ERR_INVALID, "scene is null");
+    if (int g = rt_runtime_guard()) return g;
     if (n == 0) return RT_OK;
     if (!d_rays || !d_out) return rt_fail(RT_ERR_INVALID, "null buffer");
     if (n > RT_NOALLOC_MAX_RAYS)

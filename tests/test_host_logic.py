@@ -227,7 +227,7 @@ def test_c_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", hdr))
     assert len(declared) >= 19
     assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
-    lib = ctypes.CDLL(_ffi.HIP_LIB)
+    lib = _ffi.hip_lib()   # (not ctypes.CDLL directly: the binding loads torch's HIP runtime first, see hip_lib)
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared but not exported"
     assert b"gfx950" in _ffi.hip_lib().rt_version()
@@ -242,6 +242,36 @@ def test_product_path_fails_loudly_without_a_gpu():
     with pytest.raises(_ffi.RaysError) as e:
         _ffi.Context(0)
     assert e.value.code in (-2, -1)
+
+
+def test_two_hip_runtimes_are_refused_not_aborted_on():
+    """A PyTorch wheel brings a HIP runtime of its own; loaded after this library the process holds two, and
+    handles passed between them abort inside the runtime. The library's device entry points check for that
+    first and return RT_ERR_UNSUPPORTED naming both copies. Runs in a child process, which loads the library
+    before torch (the binding itself imports torch first) and needs no device: the check comes before any
+    HIP call."""
+    import subprocess
+    import sys
+
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:
+        pytest.skip("no torch, no second runtime")
+    code = f"""
+import ctypes
+lib = ctypes.CDLL({_ffi.HIP_LIB!r}, mode=ctypes.RTLD_GLOBAL)
+lib.rt_last_error.restype = ctypes.c_char_p
+import torch
+paths = sorted({{l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}})
+h, dev = ctypes.c_void_p(), ctypes.c_int(0)
+rc = lib.rt_ctx_create(ctypes.byref(dev), 1, ctypes.byref(h))
+print(len(paths), rc, lib.rt_last_error().decode())
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n_paths, rc, msg = out.stdout.strip().splitlines()[-1].split(" ", 2)
+    if int(n_paths) < 2:
+        pytest.skip("torch uses the system's HIP runtime here")
+    assert int(rc) == -4 and "two HIP runtimes" in msg and "torch" in msg and msg.count("libamdhip64") == 2
 
 
 def test_native_libraries_do_not_link_the_oracle():
