@@ -120,6 +120,11 @@ typedef struct {
  * runs on the host only. */
 int  rt_ctx_create(const int* devices, int n, rt_ctx** out);
 void rt_ctx_destroy(rt_ctx*);
+/* The library's switches (environment variables RAYS_HIP_*, listed in INTEGRATION.md: which search
+ * a frame's rays take, limits, verbosity) are read when the context is created; this reads them
+ * again, for hosts that change them between calls (the tests and the benchmark do). No reference
+ * counterpart: the reference's switches are compile-time constants (src/main.rs:29-36). */
+int  rt_ctx_reload_env(rt_ctx*);
 
 /* ---- scene ----------------------------------------------------------------------------- */
 /* Replaces optimize_model + pack_model (src/opt.rs:11-80, src/main.rs:450-454): sorts every

@@ -87,6 +87,7 @@ _VP = C.c_void_p
 SYMBOLS = {
     "rt_ctx_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)]),
     "rt_ctx_destroy": (None, [_VP]),
+    "rt_ctx_reload_env": (C.c_int, [_VP]),
     "rt_scene_build": (C.c_int, [_VP, C.POINTER(rt_object_desc), C.c_uint32, C.POINTER(_VP)]),
     "rt_scene_build_ex": (C.c_int, [_VP, C.POINTER(rt_object_desc), C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "rt_scene_destroy": (None, [_VP]),
@@ -207,6 +208,10 @@ def render_params(width, height, grid=2, reflect_depth=4, diffuse_depth=2, diffu
     return p
 
 
+def _switches():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("RAYS_HIP_")))
+
+
 class Context:
     """rt_ctx: one GPU."""
 
@@ -215,6 +220,15 @@ class Context:
         self.handle = _VP()
         dev = C.c_int(device)
         check(self.lib.rt_ctx_create(C.byref(dev), 1, C.byref(self.handle)))
+        self._env = _switches()
+
+    def sync_env(self):
+        """The library reads its RAYS_HIP_* switches when the context is made; tests and benchmark legs set
+        them between calls, so every call through this binding has them read again if they have changed."""
+        env = _switches()
+        if env != self._env and self.handle:
+            check(self.lib.rt_ctx_reload_env(self.handle))
+            self._env = env
 
     def close(self):
         if self.handle:
@@ -323,33 +337,40 @@ class Scene:
         return r
 
     def trace_closest(self, rays):
+        self.ctx.sync_env()
         r = self._rays(rays)
         out = np.empty(len(r), dtype=HIT_DTYPE)
         check(self.lib.rt_trace_closest(self.handle, _ptr(r), len(r), _ptr(out)))
         return out
 
     def trace_closest_linear(self, rays):
+        self.ctx.sync_env()
         r = self._rays(rays)
         out = np.empty(len(r), dtype=HIT_DTYPE)
         check(self.lib.rt_trace_closest_linear(self.handle, _ptr(r), len(r), _ptr(out)))
         return out
 
     def trace_any(self, rays):
+        self.ctx.sync_env()
         r = self._rays(rays)
         out = np.empty(len(r), dtype=np.uint8)
         check(self.lib.rt_trace_any(self.handle, _ptr(r), len(r), _ptr(out)))
         return out
 
     def trace_closest_device(self, rays_ptr, n, out_ptr, stream=0):
+        self.ctx.sync_env()
         check(self.lib.rt_trace_closest_device(self.handle, rays_ptr, n, out_ptr, stream))
 
     def trace_closest_device_noalloc(self, rays_ptr, n, out_ptr, stream=0):
+        self.ctx.sync_env()
         check(self.lib.rt_trace_closest_device_noalloc(self.handle, rays_ptr, n, out_ptr, stream))
 
     def trace_any_device(self, rays_ptr, n, out_ptr, stream=0):
+        self.ctx.sync_env()
         check(self.lib.rt_trace_any_device(self.handle, rays_ptr, n, out_ptr, stream))
 
     def render(self, params, want_hit_ids=False):
+        self.ctx.sync_env()
         n_pix = params.width * params.height
         rgba = np.zeros((params.height, params.width, 4), dtype=np.uint8)
         ids = np.full(n_pix * params.grid * params.grid, RT_MISS, dtype=np.uint32) if want_hit_ids else None
@@ -357,15 +378,18 @@ class Scene:
         return (rgba, ids) if want_hit_ids else rgba
 
     def render_device(self, params, rgba_ptr, hit_ids_ptr=None, stream=0):
+        self.ctx.sync_env()
         check(self.lib.rt_render_device(self.handle, C.byref(params), rgba_ptr, hit_ids_ptr, stream))
 
     def render_device_stats(self, params, rgba_ptr, hit_ids_ptr=None):
+        self.ctx.sync_env()
         st = rt_stats()
         check(self.lib.rt_render_device_stats(self.handle, C.byref(params), rgba_ptr, hit_ids_ptr, C.byref(st)))
         return {name: getattr(st, name) for name, _ in rt_stats._fields_}
 
     def render_device_events(self, params, rgba_ptr, events, hit_ids_ptr=None, stream=0):
         """events: sequence of RT_RENDER_EVENTS raw hipEvent_t handles (ints)."""
+        self.ctx.sync_env()
         arr = (_VP * len(events))(*events)
         check(self.lib.rt_render_device_events(self.handle, C.byref(params), rgba_ptr, hit_ids_ptr, stream, arr,
                                                len(events)))

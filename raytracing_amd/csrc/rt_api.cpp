@@ -160,10 +160,28 @@ double raster_grow(const float* a, const float* b, const float* c) {
 }  // namespace
 
 
-// True when the environment variable is set and begins with `c`.
-bool env_is(const char* name, char c) {
-    const char* e = std::getenv(name);
-    return e && e[0] == c;
+void RtOptions::read_env() {
+    auto first = [](const char* name) -> char {
+        const char* e = std::getenv(name);
+        return e ? e[0] : 0;
+    };
+    auto num = [](const char* name, double none) -> double {
+        const char* e = std::getenv(name);
+        return e ? std::atof(e) : none;
+    };
+    *this = RtOptions();
+    megakernel = std::getenv("RAYS_HIP_MEGAKERNEL") != nullptr;
+    one_in_flight = (int)num("RAYS_HIP_FRAMES_IN_FLIGHT", 0.0) == 1;
+    verbose = std::getenv("RAYS_HIP_VERBOSE") != nullptr;
+    sort_rocprim = first("RAYS_HIP_SORT") == 'r';
+    cells_redo_all = first("RAYS_HIP_CELLS_REDO") == 'a';
+    raster = first("RAYS_HIP_RASTER");
+    shadow = first("RAYS_HIP_SHADOW");
+    trace = first("RAYS_HIP_TRACE");
+    bounce_rays = (long long)num("RAYS_HIP_BOUNCE_RAYS", 0.0);
+    raster_ratio = num("RAYS_HIP_RASTER_RATIO", -1.0);
+    cell_mean = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN") ? std::max(0L, (long)num("RAYS_HIP_SHADOW_CELL_MEAN", 0.0)) : -1L;
+    sort_bits = (long)num("RAYS_HIP_SORT_BITS", 0.0);
 }
 
 // A zeroed work counter for one launch on `stream` (the caller holds ctx->mu).
@@ -263,9 +281,8 @@ static double cells_mean_list(const rt_scene* s, const LightProj& lp, uint32_t k
 }
 // Longest mean list the cells are taken for (RAYS_HIP_SHADOW_CELL_MEAN overrides): the work per ray
 // grows with it, the tree walk's does not.
-static uint32_t cells_mean_limit() {
-    const char* me = std::getenv("RAYS_HIP_SHADOW_CELL_MEAN");
-    return me ? (uint32_t)std::max(0L, std::atol(me)) : 192u;
+static uint32_t cells_mean_limit(const rt_scene* s) {
+    return s->ctx->opt.cell_mean >= 0 ? (uint32_t)s->ctx->opt.cell_mean : 192u;
 }
 
 // coarse: the frame's shadow rays may go by light-space cells; then 16 key bits are kept whenever the
@@ -280,10 +297,7 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
     // rounded up to an even number, at least 16: a cell must stay narrower than the widest beam the
     // walk accepts (1/64 of the scene) or the waves stop forming beams.
     {
-        static const long env_bits = [] {
-            const char* e = std::getenv("RAYS_HIP_SORT_BITS");
-            return e ? std::atol(e) : 0L;
-        }();
+        const long env_bits = s->ctx->opt.sort_bits;
         uint32_t kb = 16;
         while (kb < 32 && ((size_t)512 << kb) < n) kb += 2;
         lp.key_bits = kb;
@@ -327,7 +341,7 @@ LightProj light_projection(const rt_scene* s, const rt_render_params* p, size_t 
     lp.vscale = (ok && v1 > v0) ? 65535.0f / (v1 - v0) : 0.0f;
     lp.uabs = ok ? std::max(std::fabs(u0), std::fabs(u1)) : 0.0f;
     lp.vabs = ok ? std::max(std::fabs(v0), std::fabs(v1)) : 0.0f;
-    if (coarse && lp.key_bits > 16 && cells_mean_list(s, lp, 16) <= 1.4 * (double)cells_mean_limit()) lp.key_bits = 16;
+    if (coarse && lp.key_bits > 16 && cells_mean_list(s, lp, 16) <= 1.4 * (double)cells_mean_limit(s)) lp.key_bits = 16;
     return lp;
 }
 
@@ -378,7 +392,8 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     const int mode = p->diffuse_depth > 1 ? 2 : ((reflective && p->reflect_depth > 1) ? 1 : 0);
     // One-kernel frame: mirror bounces without diffuse scattering (few rays, all from the sample's
     // own lane), or on request.
-    const bool pipeline = mode != 1 && !std::getenv("RAYS_HIP_MEGAKERNEL");
+    const RtOptions& opt = s->ctx->opt;
+    const bool pipeline = mode != 1 && !opt.megakernel;
     if (!pipeline) {
         HIP_TRY(mark(0));
         HIP_TRY(rtk::render(s->view, dp, d_list, mode, d_rgba8, d_hit_ids, d_stats, stream));
@@ -409,8 +424,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         // Secondary-ray records per run of tiles: at most 512 Mi (18 GB of the GPU's 288 GB as workspace,
         // allocated as far as a frame needs it); RAYS_HIP_BOUNCE_RAYS overrides. Fewer, larger runs are faster: the short
         // last run of a frame fills the device badly.
-        const char* e = std::getenv("RAYS_HIP_BOUNCE_RAYS");
-        const long long v = e ? std::atoll(e) : 0;
+        const long long v = opt.bounce_rays;
         const size_t cap = v > 0 ? (size_t)v : ((size_t)512 << 20);
         const size_t per_tile = (size_t)tile_slots * tr.branches * tr.levels;
         if (per_tile >= (1ull << 31)) return rt_fail(RT_ERR_UNSUPPORTED, "too many secondary rays per tile");
@@ -419,8 +433,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     const size_t run_slots = (size_t)run_tiles * tile_slots;
     // Two frames in flight: see rt_scene. Not for instrumented frames (their counters are read back
     // between the phases); RAYS_HIP_FRAMES_IN_FLIGHT=1 keeps every frame on the caller's stream.
-    const char* fif = std::getenv("RAYS_HIP_FRAMES_IN_FLIGHT");   // read per call: the benchmark times both ways
-    const bool one_in_flight = fif && std::atoi(fif) == 1;
+    const bool one_in_flight = opt.one_in_flight;
     const bool in_flight = mode == 0 && run_tiles == dp.n_tiles && !d_stats && !primary_stats && !one_in_flight;
     const int set = in_flight ? (int)(s->pipe_frames++ & 1u) : 0;
     FrameWork& w = set ? s->work_b : s->work;
@@ -446,10 +459,10 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     // when a triangle's box covers more than 16384 of them; by screen tile a large box costs little.
     bool raster = s->raster_ok && p->width >= p->height && p->width / p->height <= 4 &&
                   (uint64_t)p->width * p->grid < 65536u && (uint64_t)p->height * p->grid < 65536u &&  // 16-bit sample coordinates
-                  !env_is("RAYS_HIP_RASTER", '0');
+                  opt.raster != '0';
     if (raster) {
         const float aspect = (float)(p->width / p->height);
-        if (env_is("RAYS_HIP_RASTER", 'a')) {
+        if (opt.raster == 'a') {
             const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
             const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
             raster = bx * by <= 16384.0f;   // a block no sample of which passes the half-planes costs ~25 instructions
@@ -467,9 +480,8 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const double blocks = sx * sy * s->raster_sum_area + 0.7 * sx * s->raster_sum_dx + 0.7 * sy * s->raster_sum_dy +
                               0.49 * (double)s->n_tris_total;
         const double ratio = blocks * 64.0 / ((double)p->width * p->height * spp);
-        const char* lim_env = std::getenv("RAYS_HIP_RASTER_RATIO");
-        const double limit = lim_env ? std::atof(lim_env) : (env_is("RAYS_HIP_RASTER", 'a') ? 64.0 : 160.0);
-        if (std::getenv("RAYS_HIP_VERBOSE"))
+        const double limit = opt.raster_ratio >= 0.0 ? opt.raster_ratio : (opt.raster == 'a' ? 64.0 : 160.0);
+        if (opt.verbose)
             std::fprintf(stderr, "rays_hip: projection would test %.1f sample slots per sample (limit %.1f)\n", ratio, limit);
         raster = raster && ratio <= limit;
     }
@@ -479,7 +491,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
     HIP_TRY(mark(0));
     // The library's own sort moves the keys that carry a shadow ray only and leaves their number on
     // the device; RAYS_HIP_SORT=rocprim sorts all of them with the library sort instead.
-    const bool own_sort = !env_is("RAYS_HIP_SORT", 'r');
+    const bool own_sort = !opt.sort_rocprim;
     // Shadow rays by light-space cells when the scene's triangles spread thinly enough over the
     // light-space grid of the sort (decided on the device, from the lists' lengths; the tree walk
     // takes the launch otherwise). Not worth the lists for small scenes, nor for scenes whose
@@ -495,11 +507,11 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         const LightProj lp = light_projection(s, p, (size_t)dp.n_tiles * tile_slots, true);
         const size_t lc_cells = (size_t)1 << lp.key_bits;
         // RAYS_HIP_SHADOW=walk: never; =cells: whenever no list outgrows its room, however long they are on average.
-        const bool force = env_is("RAYS_HIP_SHADOW", 'c');
-        const uint32_t mean_limit = cells_mean_limit();
+        const bool force = opt.shadow == 'c';
+        const uint32_t mean_limit = cells_mean_limit(s);
         const double mean_list = cells_mean_list(s, lp, lp.key_bits);
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
-                s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && !env_is("RAYS_HIP_SHADOW", 'w') &&
+                s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && opt.shadow != 'w' &&
                 (force || (s->n_tris_total >= 32768 && mean_list <= 1.4 * (double)mean_limit));   // the estimate runs 1.4 x high on the soups
         // Room per cell: 512 entries at 2^16 cells (24 bytes each: 805 MB), 1024 when forced; 256 at 2^18.
         lc_cap_shift = lp.key_bits <= 16 ? (force ? 10u : 9u) : 8u;
@@ -540,13 +552,13 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         HIP_TRY(hipEventRecord(s->side_fork[set], ws));
         HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
         HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, lc_mean,
-                                 w.lc_flags, w.keys[0], env_is("RAYS_HIP_CELLS_REDO", 'a'), s->side_stream[set]));
+                                 w.lc_flags, w.keys[0], opt.cells_redo_all, s->side_stream[set]));
         HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
         return RT_OK;
     };
     // Projection runs tile by tile (triangle lists per tile of 32 x 32 samples, nearest hits in LDS);
     // RAYS_HIP_RASTER=atomic keeps the older form with one nearest-hit word per sample in device memory.
-    const bool raster_by_tile = raster && !env_is("RAYS_HIP_RASTER", 'a');
+    const bool raster_by_tile = raster && opt.raster != 'a';
     if (raster) {
         const size_t tab = (1 + 2 * s->objects.size()) * ((size_t)p->width + p->height) * p->grid;
         if (w.cam_table_floats < tab) {
@@ -746,6 +758,7 @@ int rt_ctx_create(const int* devices, int n, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return rt_fail(RT_ERR_NOMEM, "out of host memory");
     c->device = devices[0];
+    c->opt.read_env();
     // The allocation-free entry point's scratch array: its address on this device, looked up once.
     const int rc = rt_noalloc_setup(c);
     if (rc != RT_OK) {
@@ -753,6 +766,13 @@ int rt_ctx_create(const int* devices, int n, rt_ctx** out) {
         return rc;
     }
     *out = c;
+    return RT_OK;
+}
+
+int rt_ctx_reload_env(rt_ctx* c) {
+    if (!c) return rt_fail(RT_ERR_INVALID, "context is null");
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->opt.read_env();
     return RT_OK;
 }
 
@@ -1234,7 +1254,7 @@ int rt_trace_closest_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, rt_hi
     uint32_t* counter = nullptr;
     int rc = take_counter(s->ctx, (hipStream_t)stream, &counter);
     if (rc != RT_OK) return rc;
-    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, counter, (hipStream_t)stream));
+    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, counter, s->ctx->opt.trace, (hipStream_t)stream));
     return RT_OK;
 }
 
@@ -1249,7 +1269,7 @@ int rt_trace_any_device(rt_scene* s, const rt_ray* d_rays, uint64_t n, uint8_t* 
     uint32_t* counter = nullptr;
     int rc = take_counter(s->ctx, (hipStream_t)stream, &counter);
     if (rc != RT_OK) return rc;
-    HIP_TRY(rtk::trace_any(s->view, d_rays, n, d_occluded, counter, (hipStream_t)stream));
+    HIP_TRY(rtk::trace_any(s->view, d_rays, n, d_occluded, counter, s->ctx->opt.trace, (hipStream_t)stream));
     return RT_OK;
 }
 
@@ -1282,7 +1302,7 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* out) {
     return trace_host<rt_hit>(s, rays, n, out, [&](const rt_ray* dr, rt_hit* dout) {
         uint32_t* counter = nullptr;
         if (take_counter(s->ctx, 0, &counter) != RT_OK) return hipErrorOutOfMemory;
-        return rtk::trace_closest(s->view, dr, n, dout, counter, 0);
+        return rtk::trace_closest(s->view, dr, n, dout, counter, s->ctx->opt.trace, 0);
     });
 }
 
@@ -1290,7 +1310,7 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, uint64_t n, uint8_t* occluded)
     return trace_host<uint8_t>(s, rays, n, occluded, [&](const rt_ray* dr, uint8_t* dout) {
         uint32_t* counter = nullptr;
         if (take_counter(s->ctx, 0, &counter) != RT_OK) return hipErrorOutOfMemory;
-        return rtk::trace_any(s->view, dr, n, dout, counter, 0);
+        return rtk::trace_any(s->view, dr, n, dout, counter, s->ctx->opt.trace, 0);
     });
 }
 

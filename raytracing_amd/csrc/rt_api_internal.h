@@ -36,9 +36,29 @@ struct TileMap {
     uint32_t* d_slot = nullptr;
 };
 
+// The RAYS_HIP_* switches a frame or a batch looks at, read from the environment when the context is
+// created and again on rt_ctx_reload_env (tests and the benchmark's legs change them between calls): the
+// per-call path reads none of them from the environment.
+struct RtOptions {
+    bool megakernel = false;      // RAYS_HIP_MEGAKERNEL: one-kernel frames also where the pipeline would run
+    bool one_in_flight = false;   // RAYS_HIP_FRAMES_IN_FLIGHT=1: every frame on the caller's stream
+    bool verbose = false;         // RAYS_HIP_VERBOSE
+    bool sort_rocprim = false;    // RAYS_HIP_SORT=rocprim: the library sort for the shadow rays' keys
+    bool cells_redo_all = false;  // RAYS_HIP_CELLS_REDO=all (tests)
+    char raster = 0;              // RAYS_HIP_RASTER: '0' no projection, 'a' its older form, 0 default
+    char shadow = 0;              // RAYS_HIP_SHADOW: 'c' cells whenever they fit, 'w' tree walk, 0 default
+    char trace = 0;               // RAYS_HIP_TRACE: 'l' per-lane walk to the end, 'w' wave walks, 0 persistent walk
+    long long bounce_rays = 0;    // RAYS_HIP_BOUNCE_RAYS: secondary-ray records per run of tiles (0: default)
+    double raster_ratio = -1.0;   // RAYS_HIP_RASTER_RATIO: work limit of projection (< 0: default)
+    long cell_mean = -1;          // RAYS_HIP_SHADOW_CELL_MEAN: longest mean list the cells are taken for (< 0: default)
+    long sort_bits = 0;           // RAYS_HIP_SORT_BITS: key bits sorted on (0: by frame size)
+    void read_env();
+};
+
 struct rt_ctx {
     int device = 0;
     std::mutex mu;
+    RtOptions opt;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, TileMap> tile_maps;
     // Work counters of the persistent kernels: one per launch, taken in turn, so that launches in
     // flight on different streams do not share one.

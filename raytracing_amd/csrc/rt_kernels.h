@@ -10,11 +10,12 @@
 
 namespace rtk {
 
-// d_counter: a zeroed device word for the persistent kernel's ray hand-out.
+// d_counter: a zeroed device word for the persistent kernel's ray hand-out. how: 'l' one ray per lane to
+// the end, 'w' wave-coherent walks (nearest hit only), anything else the persistent per-lane walk.
 hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, uint32_t* d_counter,
-                         hipStream_t s);
+                         char how, hipStream_t s);
 hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, uint32_t* d_counter,
-                     hipStream_t s);
+                     char how, hipStream_t s);
 hipError_t trace_closest_linear(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out,
                                 hipStream_t s);
 hipError_t pack_tris(const float* d_verts, const uint32_t* d_tris, uint32_t n, float* d_tri9, hipStream_t s);

@@ -4065,12 +4065,10 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)(
 static inline unsigned persistent_grid(uint64_t n) { return (unsigned)std::min<uint64_t>(RT_WALK_MAX_GRID, (n + 63) / 64); }
 
 hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, rt_hit* d_out, uint32_t* d_counter,
-                         hipStream_t s) {
+                         char how, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    // RAYS_HIP_TRACE = lane: one ray per lane to the end; wave: wave-coherent walks; default: the
-    // persistent per-lane walk.
-    const char* e = std::getenv("RAYS_HIP_TRACE");
-    const int walk = !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'w' ? 2 : 0));
+    // how = 'l': one ray per lane to the end; 'w': wave-coherent walks; otherwise the persistent per-lane walk.
+    const int walk = how == 'l' ? 1 : (how == 'w' ? 2 : 0);
     if (walk == 0 && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
         hipLaunchKernelGGL(k_trace_closest_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_out);
@@ -4083,10 +4081,9 @@ hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, 
 }
 
 hipError_t trace_any(const SceneView& sv, const rt_ray* d_rays, uint64_t n, uint8_t* d_occ, uint32_t* d_counter,
-                     hipStream_t s) {
+                     char how, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    const char* e = std::getenv("RAYS_HIP_TRACE");
-    const bool lane_walk = e && e[0] == 'l';
+    const bool lane_walk = how == 'l';
     if (!lane_walk && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
         hipLaunchKernelGGL(k_trace_any_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_occ);

@@ -62,6 +62,6 @@ extern "C" int rt_trace_closest_device_noalloc(rt_scene* s, const rt_ray* d_rays
     uint32_t* counter = static_cast<uint32_t*>(ctx->noalloc_scratch);
     if (!counter) return rt_fail(RT_ERR_DEVICE, "scratch array was not set up for device %d", ctx->device);
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), (hipStream_t)stream));
-    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, counter, (hipStream_t)stream));
+    HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, counter, ctx->opt.trace, (hipStream_t)stream));
     return RT_OK;
 }

@@ -94,6 +94,7 @@ pub struct rt_stats {
 extern "C" {
     pub fn rt_ctx_create(devices: *const c_int, n: c_int, out: *mut *mut rt_ctx) -> c_int;
     pub fn rt_ctx_destroy(ctx: *mut rt_ctx);
+    pub fn rt_ctx_reload_env(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_scene_build(ctx: *mut rt_ctx, objs: *const rt_object_desc, n_objs: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_build_ex(ctx: *mut rt_ctx, objs: *const rt_object_desc, n_objs: u32, flags: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);

@@ -144,9 +144,9 @@ def test_config4_soup_10m_diffuse_bounces(soup10m, monkeypatch):
     one = g.render(render_params(W, H, 2, shard_index=5, shard_count=61, **kw))
     monkeypatch.delenv("RAYS_HIP_MEGAKERNEL")
     assert np.array_equal(one, part), f"{(one != part).sum()} bytes differ from the one-kernel frame"
-    # Strided pixels through the oracle's own frame driver, bounces and all (every 16,411th pixel:
-    # 506 pixels, about 45,000 rays over ten million triangles).
-    stride = 16411
+    # Strided pixels through the oracle's own frame driver, bounces and all (every 509th pixel:
+    # 16,297 pixels, about 1.4 million rays over ten million triangles).
+    stride = 509
     pix = np.arange(0, W * H, stride)
     ref_rgba, ref_ids, n_rays = o.render(W, H, 2, pixel_stride=stride, want_hit_ids=True, **kw)
     assert n_rays > 20 * len(pix)
@@ -184,8 +184,8 @@ def test_config5_soup_10m_8k_16spp_sharded(soup10m, ctx):
     torch.cuda.synchronize()
     assert torch.equal(out, whole), "the frame assembled from 8 shards differs from the whole frame"
     assert bool((whole[..., 3] == 255).all())
-    # every 65,537th pixel: 507 pixels, 8,112 camera rays and their shadow rays
-    stride = 65537
+    # every 2,039th pixel: 16,273 pixels, 260,368 camera rays and their shadow rays
+    stride = 2039
     pix = np.arange(0, W * H, stride)
     ref_rgba, ref_ids, _ = o.render(W, H, 4, pixel_stride=stride, want_hit_ids=True, **kw)
     pix_t = torch.from_numpy(pix).cuda()
