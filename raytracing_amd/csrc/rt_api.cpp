@@ -836,6 +836,7 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     std::vector<float> rest_verts;
     std::vector<float> bounds;                               // per packed triangle, for the tree build
 
+    std::vector<float> tree_box((size_t)n_objs * 6);         // per object: finite bounds of its vertices
     uint32_t tri_base = 0, vert_base = 0;
     for (uint32_t o = 0; o < n_objs; ++o) {
         const rt_object_desc& d = objs[o];
@@ -850,6 +851,21 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             }
         std::memcpy(ob.bbmin, mn, 12);
         std::memcpy(ob.bbmax, mx, 12);
+        // The same over the finite coordinates only: what the device tree build scales its Morton codes and
+        // its padding by (the trees hold finite boxes whatever the vertices are, see the host build below).
+        {
+            float* f = &tree_box[6 * (size_t)o];
+            for (int k = 0; k < 3; ++k) f[k] = INFINITY, f[3 + k] = -INFINITY;
+            for (uint32_t i = 0; i < d.n_verts; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const float v = d.verts[3 * (size_t)i + k];
+                    if (std::isfinite(v)) f[k] = std::min(f[k], v), f[3 + k] = std::max(f[3 + k], v);
+                }
+            for (int k = 0; k < 3; ++k)
+                if (!(f[k] <= f[3 + k])) f[k] = f[3 + k] = 0.0f;
+            // the point that stands in for a triangle with a vertex that is not finite
+            for (int k = 0; k < 3; ++k) f[k] = std::min(f[k], 0.0f), f[3 + k] = std::max(f[3 + k], 0.0f);
+        }
         // optimize_model, src/opt.rs:11-36: stable sort, smallest vertex index ascending, then
         // largest vertex index descending.
         std::vector<uint32_t>& ord = s->order[o];
@@ -1018,10 +1034,17 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             const uint32_t* t = &tris_all[3 * (size_t)(ob.tri_base + i)];
             const float *a = &verts_all[3 * (size_t)t[0]], *b = &verts_all[3 * (size_t)t[1]],
                         *c = &verts_all[3 * (size_t)t[2]];
+            bool finite = true;
             for (int k = 0; k < 3; ++k) {
                 bounds[6 * (size_t)i + k] = std::min(std::min(a[k], b[k]), c[k]);
                 bounds[6 * (size_t)i + 3 + k] = std::max(std::max(a[k], b[k]), c[k]);
+                finite = finite && std::isfinite(a[k]) && std::isfinite(b[k]) && std::isfinite(c[k]);
             }
+            // A triangle with a vertex that is not finite can be hit by no ray (its test yields infinities
+            // and NaNs the arithmetic made, which are no hit in the reference either); it gets a point for
+            // a box, so that the boxes above it stay finite and its neighbours in the tree stay reachable.
+            if (!finite)
+                for (int k = 0; k < 6; ++k) bounds[6 * (size_t)i + k] = 0.0f;
         }
         rtbvh::Result res;
         const uint32_t node_base = (uint32_t)nodes_all.size(), rec_base = (uint32_t)order_all.size();
@@ -1128,7 +1151,7 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             bool done = false;
             if (!chunked) {
                 rtk::LbvhResult res{};
-                HIP_TRY(rtk::lbvh_build_radix(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, ob.bbmin, ob.bbmax,
+                HIP_TRY(rtk::lbvh_build_radix(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, &tree_box[6 * (size_t)o], &tree_box[6 * (size_t)o + 3],
                                               ob.tri_base, slots[o].rec_base, slots[o].node_base, slots[o].wide_base, fan,
                                               d_nodes, d_wide, d_order, keys, vals, sort_tmp, tb, work, &res, 0));
                 if (3u * res.depth4 + 1u <= RT_STACK_MAX && res.depth_wide <= RT_BEAM_LEVELS) {
@@ -1143,7 +1166,7 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
             }
             if (!done) {
                 const rtk::LbvhLayout L = rtk::lbvh_layout(slots[o].n, fan);
-                HIP_TRY(rtk::lbvh_build(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, ob.bbmin, ob.bbmax,
+                HIP_TRY(rtk::lbvh_build(d_verts, d_tris + 3 * (size_t)ob.tri_base, slots[o].n, &tree_box[6 * (size_t)o], &tree_box[6 * (size_t)o + 3],
                                         ob.tri_base, slots[o].rec_base, slots[o].node_base, slots[o].wide_base, fan,
                                         d_nodes, d_wide, d_order, keys, vals, sort_tmp, tb, &ob.root, &ob.wide_root, 0));
                 s->max_stack = std::max(s->max_stack, 3u * L.depth4 + 1u);

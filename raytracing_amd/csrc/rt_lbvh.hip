@@ -42,16 +42,22 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
     return v;
 }
 
-// Exact bounds of triangle t's three vertices.
+// Exact bounds of triangle t's three vertices. A triangle with a vertex that is not finite gets the
+// point (0, 0, 0): its test can accept no ray (every product with its data is infinite or NaN, and a NaN
+// the arithmetic makes is no hit in the reference either), so it only needs a place in the tree, and an
+// infinite box would make every box above it infinite.
 __device__ __forceinline__ void tri_bounds(const float* __restrict__ verts, const uint32_t* __restrict__ tris, uint32_t t,
                                            float lo[3], float hi[3]) {
     const uint32_t ia = tris[3 * (size_t)t], ib = tris[3 * (size_t)t + 1], ic = tris[3 * (size_t)t + 2];
+    bool finite = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float a = verts[3 * (size_t)ia + k], b = verts[3 * (size_t)ib + k], c = verts[3 * (size_t)ic + k];
         lo[k] = fminf(fminf(a, b), c);
         hi[k] = fmaxf(fmaxf(a, b), c);
+        finite = finite && fabsf(a) < INFINITY && fabsf(b) < INFINITY && fabsf(c) < INFINITY;
     }
+    if (!finite) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
 }
 
 // 30-bit Morton code of every triangle's box centre inside the object's box.

@@ -160,3 +160,40 @@ def test_camera_rays_of_large_slivers_and_edge_on_triangles(ctx, oracle, monkeyp
     finally:
         g.close()
         o.close()
+
+
+@pytest.mark.parametrize("device_build", [False, True])
+def test_a_vertex_that_is_not_finite_hides_nothing_else(ctx, oracle, monkeypatch, device_build):
+    """Triangles with an infinite coordinate can be hit by no ray (their test yields infinities and NaNs
+    made by the arithmetic, which the reference does not accept either), but they sit in the tree among
+    the others: every walk must still find every other triangle, as the reference-order scan and the
+    oracle do. (An infinite box used to make every box above it infinite, and the compact form of the
+    nodes dropped such children.)"""
+    objs = scenes.soup(32768, 0x5EED0021)
+    v = objs[0]["verts"].copy().reshape(-1, 3, 3)
+    v[17, 0, 0] = np.inf
+    v[18000, 2, 1] = -np.inf
+    v[32000, 1, 2] = np.inf
+    objs[0]["verts"] = v.reshape(-1, 3)
+    if device_build:
+        monkeypatch.setenv("RAYS_HIP_BUILD", "device")
+    g, o = Scene(ctx, objs), oracle.OracleScene(objs)
+    try:
+        rays = scenes.camera_rays(160, 90, 2)
+        ref = o.trace_closest(rays)
+        assert (ref["tri"] != RT_MISS).mean() > 0.05 and not np.isin(ref["tri"], [17, 18000, 32000]).any()
+        _bit_equal(g.trace_closest(rays), ref)
+        _bit_equal(g.trace_closest_linear(rays), ref)
+        for mode in ("lane", "wave"):
+            monkeypatch.setenv("RAYS_HIP_TRACE", mode)
+            _bit_equal(g.trace_closest(rays), ref)
+            monkeypatch.delenv("RAYS_HIP_TRACE")
+        assert np.array_equal(g.trace_any(rays), o.trace_any(rays))
+        kw = dict(reflect_depth=1, diffuse_depth=1, sun=(3.0, 40.0, -30.0))
+        ref_rgba, ref_ids, _ = o.render(160, 90, 2, want_hit_ids=True, **kw)
+        rgba, ids = g.render(render_params(160, 90, 2, **kw), want_hit_ids=True)
+        assert np.array_equal(ids, ref_ids)
+        assert np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max() <= 1
+    finally:
+        g.close()
+        o.close()

@@ -41,3 +41,32 @@ def test_no_alloc_entry_point_equals_trace_closest_device(ctx, oracle, soup64k):
             g.trace_closest_device_noalloc(1, (1 << 31) + 1, 1, 0)
     finally:
         g.close()
+
+
+def test_no_alloc_entry_point_allocates_nothing_and_shares_one_array_per_gpu(ctx, soup64k):
+    """The device's free memory is the same before and after the call (hipMemGetInfo through torch, which
+    allocates nothing itself once the buffers exist), and a second context on the same GPU uses the same
+    per-GPU array: calls through the two, one after the other on one stream, give the same hits."""
+    import torch
+
+    from raytracing_amd import Context
+
+    ctx2 = Context(0)
+    g, g2 = Scene(ctx, soup64k), Scene(ctx2, soup64k)
+    try:
+        rays = scenes.camera_rays(160, 90, 2)
+        d_rays = torch.from_numpy(rays).cuda()
+        outs = [torch.full((len(rays) * 4,), -1, dtype=torch.int32, device="cuda") for _ in range(3)]
+        sh = torch.cuda.current_stream().cuda_stream
+        g.trace_closest_device(d_rays.data_ptr(), len(rays), outs[0].data_ptr(), sh)   # takes its counter pool on first use
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        g.trace_closest_device_noalloc(d_rays.data_ptr(), len(rays), outs[1].data_ptr(), sh)
+        g2.trace_closest_device_noalloc(d_rays.data_ptr(), len(rays), outs[2].data_ptr(), sh)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "the allocation-free entry point changed the device's free memory"
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        g.close()
+        g2.close()
+        ctx2.close()
