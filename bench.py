@@ -70,6 +70,65 @@ def cpu_baseline(objects, width, height, target_seconds=20.0):
     }
 
 
+def teapot_leg(ctx, args, with_cpu):
+    """The reference's own scene (src/main.rs:406-448: two teapots and a two-triangle floor, 12,642
+    triangles, sun frozen at t = 0) at 1920x1080 with four samples a pixel, camera + shadow rays
+    (config 2 of the metric), timed like the headline: K frames between synchronisations, one frame at a
+    time. Beside it the same scene with the reference's full constants at its own 800x800 (mirror depth 4,
+    ten scatter rays off every camera hit), and the CPU oracle on the whole config-2 frame."""
+    import torch
+
+    from raytracing_amd import Scene, render_params, scenes
+
+    objects = scenes.default_scene()
+    scene = Scene(ctx, objects)
+    sh = torch.cuda.current_stream().cuda_stream
+    out = {"workload": "the reference's default scene (two teapots + floor, 12,642 triangles, sun at t = 0), 1920x1080, "
+                       "4 samples/pixel, primary + sun-shadow rays, shade + resolve to RGBA8 on device"}
+
+    def timed(p, steps):
+        frame = torch.zeros((p.height, p.width, 4), dtype=torch.uint8, device="cuda")
+        st = scene.render_device_stats(p, frame.data_ptr())
+        for _ in range(3):
+            scene.render_device(p, frame.data_ptr(), None, sh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scene.render_device(p, frame.data_ptr(), None, sh)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return st, dt
+
+    W, H = 1920, 1080
+    st, dt = timed(render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0), args.steps)
+    out.update({"mrays_per_s": st["rays"] / dt / 1e6, "ms_per_frame": dt * 1e3, "rays_per_frame": st["rays"],
+                "camera_rays_by": "projection" if st["camera_by_projection"] else "beam walk",
+                "shadow_rays_by": "light-space cells" if st["shadow_by_cells"] else "beam walk",
+                "box_tests_per_ray": st["box_tests"] / max(1, st["rays"]), "tri_tests_per_ray": st["tri_tests"] / max(1, st["rays"])})
+    os.environ["RAYS_HIP_FRAMES_IN_FLIGHT"] = "2"
+    _, dt2 = timed(render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0), args.steps)
+    os.environ["RAYS_HIP_FRAMES_IN_FLIGHT"] = "1"
+    out["two_frames_in_flight"] = {"mrays_per_s": st["rays"] / dt2 / 1e6, "ms_per_frame": dt2 * 1e3}
+    st8, dt8 = timed(render_params(800, 800, 2, reflect_depth=4, diffuse_depth=2, diffuse_scatt=10, sun=scenes.SUN_T0, seed=1),
+                     max(3, args.steps // 4))
+    out["reference_constants_800x800"] = {"mrays_per_s": st8["rays"] / dt8 / 1e6, "ms_per_frame": dt8 * 1e3,
+                                          "rays_per_frame": st8["rays"], "frames_per_s": 1.0 / dt8}
+    scene.close()
+    if with_cpu:
+        from oracle import oracle_ffi as O
+
+        cores = O.default_threads()
+        sc = O.OracleScene(objects)
+        t0 = time.perf_counter()
+        _, _, rays = sc.render(W, H, grid=2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0, n_threads=cores)
+        dtc = time.perf_counter() - t0
+        sc.close()
+        out["cpu_oracle"] = {"mrays_per_s": rays / dtc / 1e6, "cores": cores, "kind": "port",
+                             "sample": f"the whole {W}x{H} frame, 4 samples a pixel: {rays} rays in {dtc:.1f} s"}
+        out["gpu_over_cpu"] = out["mrays_per_s"] / out["cpu_oracle"]["mrays_per_s"]
+    return out
+
+
 def bounce_roofline(ctx, args, new_event, elapsed_ms):
     """A short run of the diffuse-bounce workload (config 4: soup-10M, 3840x2160, four samples, ten
     scatter rays off every hit and the shadow rays of all of them): frame time, and the roofline
@@ -500,6 +559,7 @@ def main():
         if world == 1 and not args.no_extras:
             # Free the headline scene's frame workspace before the 10M-triangle scene comes in.
             scene.close()
+            out["teapot"] = teapot_leg(ctx, args, not args.no_cpu_baseline)
             out["roofline_bounce"] = bounce_roofline(ctx, args, new_event, elapsed_ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objects, W, H)

@@ -462,6 +462,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
                   opt.raster != '0';
     if (raster) {
         const float aspect = (float)(p->width / p->height);
+        if (opt.raster == 'a' && s->n_rest_total != 0) raster = false;   // the older form does not test trailing triangles
         if (opt.raster == 'a') {
             const float bx = s->raster_dx * (float)(p->width * p->grid) * 0.5f / aspect / 8.0f + 2.0f;
             const float by = s->raster_dy * (float)(p->height * p->grid) * 0.5f / 8.0f + 2.0f;
@@ -911,10 +912,25 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     s->n_leaves = (uint32_t)leaf_first.size();
     s->n_tris_total = tri_base;
     s->raster_ok = n_objs <= 16;
+    {
+        // Trailing n % 8 triangles never lower `closest` (src/main.rs:157-169), so what they are compared
+        // with depends on the objects before them. Projection takes the scenes in which that is the
+        // nearest eight-wide hit of the whole scene: no eight-wide triangle after a trailing one in object
+        // order (the reference's own scene: two teapots of whole leaves, then a floor of two triangles).
+        uint32_t first_rest = n_objs, last_packed = 0;
+        s->n_rest_total = 0;
+        for (uint32_t o = 0; o < n_objs; ++o) {
+            const DevObject& ob = s->objects[o];
+            if (ob.n_rest != 0 && first_rest == n_objs) first_rest = o;
+            if (ob.n_tris > ob.n_rest) last_packed = o;
+            s->n_rest_total += ob.n_rest;
+        }
+        if (first_rest < last_packed) s->raster_ok = false;
+        if (s->n_rest_total == s->n_tris_total) s->raster_ok = false;   // nothing to project
+    }
     for (uint32_t o = 0; o < n_objs && s->raster_ok; ++o) {
         const DevObject& ob = s->objects[o];
-        if (ob.n_rest != 0) s->raster_ok = false;
-        for (uint32_t i = 0; i < ob.n_tris && s->raster_ok; ++i) {
+        for (uint32_t i = 0; i < ob.n_tris - ob.n_rest && s->raster_ok; ++i) {
             const uint32_t* t = &tris_all[3 * (size_t)(ob.tri_base + i)];
             const float *a = &verts_all[3 * (size_t)t[0]], *b = &verts_all[3 * (size_t)t[1]], *c = &verts_all[3 * (size_t)t[2]];
             float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
@@ -1212,8 +1228,12 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     s->view.tri9 = d_tri9;
     s->view.leaf_bounds = d_leaf_bounds;
     s->view.leaf_gate = d_leaf_gate;
+    // triangle id lies in leaf id / 8 as long as no object with trailing triangles comes before it
     s->view.leaves_uniform = 1u;
-    for (const DevObject& ob : s->objects) s->view.leaves_uniform = (s->view.leaves_uniform && ob.n_rest == 0) ? 1u : 0u;
+    s->view.n_rest_total = s->n_rest_total;
+    for (size_t o = 0; o < s->objects.size(); ++o)
+        for (size_t later = o + 1; later < s->objects.size() && s->objects[o].n_rest != 0; ++later)
+            if (s->objects[later].n_tris > s->objects[later].n_rest) s->view.leaves_uniform = 0u;
     s->view.tri_data = d_data;
     s->view.rest_verts = d_rest;
     s->device_ptrs = pool.ptrs;

@@ -159,6 +159,7 @@ struct rt_scene {
     // triangle's patch is likely to touch (the estimate that decides whether the lists are tried).
     double mean_tri_side[3] = {0.0, 0.0, 0.0};
     uint32_t n_tris_total = 0;
+    uint32_t n_rest_total = 0;   // trailing n % 8 triangles of all objects together
     SceneView view{};
     std::vector<void*> device_ptrs;
     uint32_t n_tris = 0;

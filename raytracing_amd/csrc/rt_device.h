@@ -51,6 +51,7 @@ struct SceneView {
                                 // packet of eight (PackedBoxes::intersect), 0 for one of an object's last
                                 // n_leaves % 8 (box_intersection_check): what ref_leaf_gate reads
     uint32_t leaves_uniform;    // 1: no object has trailing triangles, so triangle id lies in leaf id / 8
+    uint32_t n_rest_total;      // trailing triangles of all objects together
     const float* tri_data;      // reference order: normal xyz, color rgb per triangle
     const float* rest_verts;    // a xyz, b xyz, c xyz of every trailing triangle
     float beam_limit;           // widest beam footprint worth a beam walk (scene extent / 128)

@@ -2277,6 +2277,8 @@ __device__ __forceinline__ RasterTri raster_prepare(const SceneView& sv, const D
         }
     }
     if (!rt.rs.visible) mu1 = mu0 - 1;
+    // an object's trailing n % 8 triangles are not projected: the tile kernel tests them sample by sample
+    if (id - ob.tri_base >= ob.n_tris - ob.n_rest) mu1 = mu0 - 1;
     rt.u0 = mu0, rt.u1 = mu1, rt.w0 = mw0, rt.w1 = mw1;
     // The object's box test (src/main.rs:101, src/objects.rs:322-333) with the origin at zero is
     // g_min(t_near, 0) <= t_far. When the box holds the view axis on both lateral axes and reaches
@@ -3109,6 +3111,8 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         }
         // The reference tests a triangle only for rays that pass the box of its leaf (ref_leaf_gate): the
         // nearest hit is checked against it, and the few samples whose nearest hit fails are worked out again.
+        // (A projected scene's eight-wide triangles fill whole leaves from triangle 0 on: objects with
+        // trailing triangles come last, see rt_scene_build.)
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
             const rt_f3 inv = f3(lds.idx[sul[u]], lds.idy[swl[u]], 1.0f);
@@ -3120,6 +3124,38 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                 hs[u].obj = 0;
                 while (hs[u].obj + 1 < sv.n_objs && hs[u].tri >= sv.objs[hs[u].obj].tri_base + sv.objs[hs[u].obj].n_tris) ++hs[u].obj;
                 normal[u] = ld3(sv.tri_data + 6 * (size_t)hs[u].tri);
+            }
+        }
+        // The objects' trailing n % 8 triangles (src/main.rs:157-169), which the reference tests one by one
+        // after an object's eight-wide ones and which never lower `closest`: the last of them nearer
+        // than the nearest eight-wide hit wins. Projection takes scenes in which no eight-wide triangle
+        // follows a trailing one in object order, so `closest` is the nearest eight-wide hit of the whole
+        // scene for every one of them, and "the last" is found by going through them backwards.
+        if (sv.n_rest_total != 0u) {
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                if (!inside[u]) continue;
+                const rt_f3 d = f3(lds.dx[sul[u]], lds.dy[swl[u]], 1.0f);
+                const float closest = hit_any[u] ? hs[u].t : RT_INF;
+                bool found = false;
+                for (uint32_t oi = sv.n_objs; oi-- > 0u && !found;) {
+                    const DevObject& ob = sv.objs[oi];
+                    if (ob.n_rest == 0u) continue;
+                    if (!raster_object_box(sv, tab, L, gw, oi, (uint32_t)su0 + sul[u], (uint32_t)sw0 + swl[u])) continue;
+                    for (uint32_t r = ob.n_rest; r-- > 0u && !found;) {
+                        const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
+                        float t, bu, bv;
+                        if (STATS) st.tri += 1;
+                        if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, closest, &t, &bu, &bv)) {
+                            found = true;
+                            hit_any[u] = true;
+                            hs[u].tri = ob.tri_base + ob.n_tris - ob.n_rest + r;
+                            hs[u].obj = oi;
+                            hs[u].t = t;
+                            normal[u] = ld3(sv.tri_data + 6 * (size_t)hs[u].tri);
+                        }
+                    }
+                }
             }
         }
 #pragma unroll

@@ -394,7 +394,10 @@ def test_projection_is_left_to_scenes_it_fits(ctx, soup64k, default_objects, mon
     assert _stats(g, render_params(1920, 1080, 2, reflect_depth=1, diffuse_depth=1))["camera_by_projection"] == 1
     g.close()
     monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
-    g = Scene(ctx, default_objects)          # the floor is two trailing triangles
+    g = Scene(ctx, default_objects)          # the floor's two trailing triangles come last: projected
+    assert _stats(g, p)["camera_by_projection"] == 1
+    g.close()
+    g = Scene(ctx, [default_objects[2], default_objects[0]])   # trailing triangles before eight-wide ones
     assert _stats(g, p)["camera_by_projection"] == 0
     g.close()
     behind = dict(soup64k[0])

@@ -197,3 +197,52 @@ def test_a_vertex_that_is_not_finite_hides_nothing_else(ctx, oracle, monkeypatch
     finally:
         g.close()
         o.close()
+
+
+def _projected_frame_check(ctx, oracle, objs, monkeypatch, sizes, expect_projection=True):
+    import torch
+
+    g, o = Scene(ctx, objs), oracle.OracleScene(objs)
+    try:
+        monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
+        for (W, H, grid) in sizes:
+            kw = dict(reflect_depth=1, diffuse_depth=1, sun=(3.0, 40.0, -30.0))
+            p = render_params(W, H, grid, **kw)
+            frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            assert g.render_device_stats(p, frame.data_ptr())["camera_by_projection"] == int(expect_projection)
+            rgba, ids = g.render(p, want_hit_ids=True)
+            ref_rgba, ref_ids, _ = o.render(W, H, grid, want_hit_ids=True, **kw)
+            assert np.array_equal(ids, ref_ids), f"{(ids != ref_ids).sum()} hit ids differ at {W}x{H}x{grid}"
+            assert np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max() <= 1
+            monkeypatch.setenv("RAYS_HIP_RASTER", "0")
+            rgba_walk, ids_walk = g.render(p, want_hit_ids=True)
+            monkeypatch.delenv("RAYS_HIP_RASTER")
+            assert np.array_equal(ids_walk, ids) and np.array_equal(rgba_walk, rgba)
+    finally:
+        g.close()
+        o.close()
+
+
+def test_projection_with_trailing_triangles_after_the_eight_wide_ones(ctx, oracle, monkeypatch):
+    """Camera rays by projection in scenes whose trailing n % 8 triangles all come after the last
+    eight-wide triangle in object order (the reference's own scene is one: two teapots of whole leaves,
+    then a floor of two triangles): the trailing triangles are tested sample by sample against the nearest
+    eight-wide hit of the whole scene, the last one that beats it wins. In any other order that distance
+    depends on the objects in between, and the frame is left to the tree walk."""
+    a = _obj([7.0, 6.0, 8.0], shift=(-0.4, 0.1))                                      # 3 trailing
+    b = _obj([6.5 + 0.25 * i for i in range(8)], shift=(0.3, -0.2), scale=1.5)         # one leaf
+    c = _obj([9.0 - 0.3 * i for i in range(11)], shift=(0.0, 0.3), scale=2.0)          # one leaf + 3 trailing
+    d = _obj([5.5 + 0.2 * ((7 * i) % 19) for i in range(19)], shift=(0.2, 0.0), scale=1.2)   # two leaves + 3 trailing
+    e = _obj([10.0, 4.0], shift=(0.1, -0.1), scale=3.0)                                # 2 trailing, one in front of everything
+    sizes = [(96, 64, 2), (50, 30, 4)]
+    for order in ([b, c, a], [b, d, a, e], [b, b, d], [d], [b, e]):
+        _projected_frame_check(ctx, oracle, order, monkeypatch, sizes)
+    for order in ([a, b], [c, b], [b, c, d]):
+        _projected_frame_check(ctx, oracle, order, monkeypatch, sizes[:1], expect_projection=False)
+
+
+def test_default_scene_by_projection(ctx, oracle, default_objects, monkeypatch):
+    """The reference's own scene (src/main.rs:406-448): the floor's two triangles are trailing triangles
+    10,000 units wide that pass behind the camera; the teapots are projected, the floor is tested per
+    sample."""
+    _projected_frame_check(ctx, oracle, default_objects, monkeypatch, [(320, 180, 2), (200, 200, 1), (160, 90, 4)])

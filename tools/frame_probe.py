@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Phase times and per-wave counters of the benchmark frame under the current environment knobs.
-usage: python dbg/knobs.py [label]"""
+usage: [PROBE_SCENE=teapot|<triangles>] [PROBE_W=.. PROBE_H=..] python tools/frame_probe.py [label]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracing_amd import Context, Scene, render_params, scenes
 
-W, H = 3840, 2160
-objects = scenes.soup(1_000_000, 0x5EED0001)
+W, H = int(os.environ.get("PROBE_W", "3840")), int(os.environ.get("PROBE_H", "2160"))
+which = os.environ.get("PROBE_SCENE", "1000000")
+objects = scenes.default_scene() if which == "teapot" else scenes.soup(int(which), 0x5EED0001)
 ctx = Context(0)
 scene = Scene(ctx, objects)
 p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0)
