@@ -129,7 +129,68 @@ def teapot_leg(ctx, args, with_cpu):
     return out
 
 
-def bounce_roofline(ctx, args, new_event, elapsed_ms):
+def config5_leg(ctx, args, rank, world, comm, dist, red_dev, scene=None):
+    """Config 5 of the metric: soup-10M at 7680x4320 with 4 x 4 samples a pixel, camera + shadow rays, the
+    frame's tiles dealt out to the ranks and gathered on rank 0 (the configuration the tile split was
+    designed for: its per-ray work dwarfs a rank's fixed set-up). K // 4 frames between fences."""
+    import torch
+
+    from raytracing_amd import Scene, render_params, scenes
+    from raytracing_amd import distributed as rd
+
+    W, H = 7680, 4320
+    own = scene is None
+    if own:
+        scene = Scene(ctx, scenes.soup(args.bounce_tris, 0x5EED0002))
+    p = render_params(W, H, 4, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0, shard_index=rank, shard_count=world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream()
+    sh = stream.cuda_stream
+    if world == 1:
+        bufs = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)]
+        full = None
+    else:
+        slab_bytes = rd.slab_tiles(W, H, world) * rd.TILE_BYTES
+        bufs = [torch.zeros(slab_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        full = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    st = scene.render_device_stats(p, bufs[0].data_ptr())
+    rays = torch.tensor([st["rays"]], dtype=torch.int64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(rays)
+
+    def frame(i):
+        b = bufs[i % len(bufs)]
+        scene.render_device(p, b.data_ptr(), None, sh)
+        if world > 1 and comm is not None:
+            comm.gather_tiles_device(b.data_ptr(), W, H, full.data_ptr() if rank == 0 else None, sh)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps = max(3, args.steps // 4)
+    for i in range(2):
+        frame(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        frame(i)
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item()) / steps
+    if own:
+        scene.close()
+    return {"workload": f"soup-{args.bounce_tris} seed 0x5eed0002, {W}x{H}, 16 samples/pixel, primary + sun-shadow rays, "
+                        f"tiles over {world} rank(s)" + (", gathered on rank 0 by rt_gather_tiles_device" if world > 1 and comm is not None else ""),
+            "value": int(rays.item()) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "rays_per_frame": int(rays.item()), "n_gpus": world}
+
+
+def bounce_roofline(ctx, args, new_event, elapsed_ms, scene):
     """A short run of the diffuse-bounce workload (config 4: soup-10M, 3840x2160, four samples, ten
     scatter rays off every hit and the shadow rays of all of them): frame time, and the roofline
     of k_wf_bounce, the persistent per-lane walk that traces the scatter rays. One launch = one level
@@ -142,9 +203,6 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
     # One run of tiles for the whole frame (the default workspace limit would cut this frame in two, and
     # the events around the bounce launches cover one run).
     os.environ.setdefault("RAYS_HIP_BOUNCE_RAYS", str(-(-W // 32) * -(-H // 32) * 1024 * 4 * 10))
-    objects = scenes.soup(args.bounce_tris, 0x5EED0002)
-    scene = Scene(ctx, objects)
-    del objects
     p = render_params(W, H, 2, reflect_depth=4, diffuse_depth=2, diffuse_scatt=10, sun=scenes.SUN_T0, seed=1)
     frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
     sh = torch.cuda.current_stream().cuda_stream
@@ -160,7 +218,6 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms):
     dt = (time.perf_counter() - t0) / n
     bounce_ms = float(np.mean([elapsed_ms(ev[5], ev[6]) for ev in events]))
     sizes = scene.sizes()
-    scene.close()
     # Unit = one scatter ray; one launch = the scatter rays of one frame (st["bounce_rays"] of them,
     # out of samples * 10 ray slots: samples that hit nothing cast none). Algorithmic bytes of a
     # launch: per slot a 24-byte record out (hit point + id 16, state 4, sort key 4), per sample
@@ -426,6 +483,12 @@ def main():
         torch.cuda.synchronize()
         frame_ok = bool(torch.equal(whole, full))
     phase_ms = [float(np.mean([elapsed_ms(ev[k], ev[k + 1]) for ev in phase_events])) for k in range(4)]
+    # Config 5 on every rank (multi-rank runs; a single GPU runs it with the other extras below).
+    config5 = None
+    sizes = scene.sizes()
+    if world > 1 and not args.no_extras and (comm is not None or backend != "nccl"):   # (a rehearsal renders without the gather)
+        scene.close()
+        config5 = config5_leg(ctx, args, rank, world, comm, dist, red_dev)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total * args.steps / elapsed / 1e6
@@ -436,7 +499,6 @@ def main():
         # triangle record a wave fetches, from the kernel's own counters in the instrumented build):
         # per-ray structure bytes at the granularity the loads are issued. Its ratio to `traffic` is
         # the cache amplification.
-        sizes = scene.sizes()
         n_samples_rank = st["primary_rays"]
         n_shadow_rank = st["rays"] - st["primary_rays"]
         projected = bool(st["camera_by_projection"])
@@ -560,7 +622,15 @@ def main():
             # Free the headline scene's frame workspace before the 10M-triangle scene comes in.
             scene.close()
             out["teapot"] = teapot_leg(ctx, args, not args.no_cpu_baseline)
-            out["roofline_bounce"] = bounce_roofline(ctx, args, new_event, elapsed_ms)
+            t0 = time.perf_counter()
+            scene10 = Scene(ctx, scenes.soup(args.bounce_tris, 0x5EED0002))
+            build10_s = time.perf_counter() - t0
+            out["roofline_bounce"] = bounce_roofline(ctx, args, new_event, elapsed_ms, scene10)
+            out["roofline_bounce"]["scene_generate_and_build_s"] = build10_s
+            out["config5"] = config5_leg(ctx, args, 0, 1, None, dist, red_dev, scene10)
+            scene10.close()
+        if config5 is not None:
+            out["config5"] = config5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objects, W, H)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
