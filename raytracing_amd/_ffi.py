@@ -17,6 +17,7 @@ HOST_LIB = os.path.join(LIB_DIR, "librays_host.so")
 RT_MISS = 0xFFFFFFFF
 RT_TILE = 32
 RT_BUILD_DEVICE = 1
+RT_BUILD_HOST = 2
 
 
 class RaysError(RuntimeError):
@@ -76,6 +77,7 @@ class rt_stats(C.Structure):
         ("shadow_list_longest", C.c_uint64),
         ("shadow_list_cells", C.c_uint64),
         ("shadow_redone", C.c_uint64),
+        ("tree_built_on_device", C.c_uint64),
     ]
 
 
@@ -283,17 +285,16 @@ class Comm:
 class Scene:
     """rt_scene: the packed World on one GPU."""
 
-    def __init__(self, ctx, objects, device_build=False):
+    def __init__(self, ctx, objects, device_build=None):
         self.ctx = ctx
         self.lib = ctx.lib
         self.n_objs = len(objects)
         self.obj_tris = [len(np.asarray(o["tris"]).reshape(-1, 3)) for o in objects]
         descs, keep = make_descs(objects)
         self.handle = _VP()
-        if device_build:
-            check(self.lib.rt_scene_build_ex(ctx.handle, descs, len(objects), RT_BUILD_DEVICE, C.byref(self.handle)))
-        else:
-            check(self.lib.rt_scene_build(ctx.handle, descs, len(objects), C.byref(self.handle)))
+        # device_build: True / False say where the trees are built, None leaves it to the library (by size).
+        flags = 0 if device_build is None else (RT_BUILD_DEVICE if device_build else RT_BUILD_HOST)
+        check(self.lib.rt_scene_build_ex(ctx.handle, descs, len(objects), flags, C.byref(self.handle)))
         del keep
 
     def close(self):

@@ -797,7 +797,8 @@ int rt_scene_build(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, rt_
 
 int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, uint32_t flags, rt_scene** out) {
     if (!out) return rt_fail(RT_ERR_INVALID, "out is null");
-    if (flags & ~(uint32_t)RT_BUILD_DEVICE) return rt_fail(RT_ERR_INVALID, "unknown build flags %#x", flags);
+    if (flags & ~(uint32_t)(RT_BUILD_DEVICE | RT_BUILD_HOST)) return rt_fail(RT_ERR_INVALID, "unknown build flags %#x", flags);
+    if ((flags & RT_BUILD_DEVICE) && (flags & RT_BUILD_HOST)) return rt_fail(RT_ERR_INVALID, "RT_BUILD_DEVICE and RT_BUILD_HOST together");
     *out = nullptr;
     if (!ctx || !objs || n_objs == 0) return rt_fail(RT_ERR_INVALID, "ctx / objs null or no objects");
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -1002,9 +1003,22 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     const int nt = host_threads();
     uint32_t wide_width = 64;
     if (const char* e = std::getenv("RAYS_HIP_WIDE")) wide_width = (uint32_t)std::atoi(e);
-    // RT_BUILD_DEVICE (or RAYS_HIP_BUILD=device): the trees are built on the device after the upload.
-    bool device_build = (flags & RT_BUILD_DEVICE) != 0u;
-    if (const char* e = std::getenv("RAYS_HIP_BUILD")) device_build = device_build || std::strcmp(e, "device") == 0;
+    // Where the trees are built. The host's surface-area build gives the walks 4 to 12 % faster trees on
+    // scenes of one to three million triangles; from about ten million on the device's radix trees are as
+    // fast to walk (measured on triangle soups, the camera, shadow and scatter walks alike) and are built in
+    // under a second where the host needs several. So: on the device from DEVICE_BUILD_FROM triangles on,
+    // unless the caller says which (RT_BUILD_DEVICE / RT_BUILD_HOST, or RAYS_HIP_BUILD=device|host).
+    constexpr uint32_t DEVICE_BUILD_FROM = 4000000u;
+    uint32_t n_in_trees = 0;
+    for (uint32_t o = 0; o < n_objs; ++o) n_in_trees += (s->objects[o].n_tris / 8) * 8;
+    bool device_build = n_in_trees >= DEVICE_BUILD_FROM;
+    if (const char* e = std::getenv("RAYS_HIP_BUILD")) {
+        if (std::strcmp(e, "device") == 0) device_build = true;
+        if (std::strcmp(e, "host") == 0) device_build = false;
+    }
+    if (flags & RT_BUILD_DEVICE) device_build = true;
+    if (flags & RT_BUILD_HOST) device_build = false;
+    s->built_on_device = device_build;
     struct TreeSlot {
         uint32_t node_base = 0, wide_base = 0, rec_base = 0, n = 0;
     };
@@ -1416,6 +1430,7 @@ int rt_render_device_stats(rt_scene* s, const rt_render_params* p, uint8_t* d_rg
     stats->shadow_list_longest = lf[2];
     stats->shadow_list_cells = lf[3];
     stats->shadow_redone = lf[5];
+    stats->tree_built_on_device = s->built_on_device ? 1u : 0u;
     DevStats h;
     HIP_TRY(hipMemcpy(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost));
     stats->rays = h.rays;

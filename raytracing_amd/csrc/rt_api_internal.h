@@ -160,6 +160,7 @@ struct rt_scene {
     double mean_tri_side[3] = {0.0, 0.0, 0.0};
     uint32_t n_tris_total = 0;
     uint32_t n_rest_total = 0;   // trailing n % 8 triangles of all objects together
+    bool built_on_device = false;
     SceneView view{};
     std::vector<void*> device_ptrs;
     uint32_t n_tris = 0;

@@ -4,6 +4,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 pub const RT_MISS: u32 = 0xFFFF_FFFF;
 pub const RT_BUILD_DEVICE: u32 = 1;
+pub const RT_BUILD_HOST: u32 = 2;
 pub const RT_TILE: u32 = 32;
 pub const RT_RENDER_EVENTS: c_int = 8;
 
@@ -89,6 +90,7 @@ pub struct rt_stats {
     pub shadow_list_longest: u64,
     pub shadow_list_cells: u64,
     pub shadow_redone: u64,
+    pub tree_built_on_device: u64,
 }
 
 extern "C" {

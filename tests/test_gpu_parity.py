@@ -627,6 +627,47 @@ def test_device_built_tree_gives_the_same_answers(which, ctx, oracle, default_ob
     g.close()
 
 
+def test_where_the_trees_are_built(ctx, soup64k, monkeypatch):
+    """Neither flag: by size (a scene of 64 k triangles on the host). RT_BUILD_DEVICE / RT_BUILD_HOST and
+    RAYS_HIP_BUILD=device|host say which; a flag wins over the environment; both flags are refused. The
+    hits are the same wherever the trees come from."""
+    import ctypes as C
+
+    from raytracing_amd import _ffi
+
+    rays = scenes.camera_rays(96, 54, 1)
+    p = render_params(64, 36, 1, reflect_depth=1, diffuse_depth=1)
+
+    def built(**kw):
+        g = Scene(ctx, soup64k, **kw)
+        try:
+            import torch
+            frame = torch.zeros((36, 64, 4), dtype=torch.uint8, device="cuda")
+            return g.render_device_stats(p, frame.data_ptr())["tree_built_on_device"], g.trace_closest(rays)
+        finally:
+            g.close()
+
+    monkeypatch.delenv("RAYS_HIP_BUILD", raising=False)
+    on_dev, want = built()
+    assert on_dev == 0
+    for kw, env, expect in ((dict(device_build=True), None, 1), (dict(device_build=False), "device", 0),
+                            (dict(), "device", 1), (dict(device_build=True), "host", 1)):
+        if env is None:
+            monkeypatch.delenv("RAYS_HIP_BUILD", raising=False)
+        else:
+            monkeypatch.setenv("RAYS_HIP_BUILD", env)
+        on_dev, got = built(**kw)
+        assert on_dev == expect, (kw, env)
+        assert np.array_equal(got["tri"], want["tri"])
+        assert np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32))
+    monkeypatch.delenv("RAYS_HIP_BUILD", raising=False)
+    descs, keep = _ffi.make_descs(soup64k)
+    h = C.c_void_p()
+    rc = ctx.lib.rt_scene_build_ex(ctx.handle, descs, len(soup64k), _ffi.RT_BUILD_DEVICE | _ffi.RT_BUILD_HOST, C.byref(h))
+    assert rc != 0 and not h.value
+    assert ctx.lib.rt_scene_build_ex(ctx.handle, descs, len(soup64k), 4, C.byref(h)) != 0 and not h.value
+
+
 def test_gather_tiles_over_a_one_rank_rccl_communicator(ctx):
     """rt_comm_id_create / rt_comm_create / rt_gather_tiles_device with the only communicator one GPU
     allows: a single rank. Rank 0's own slab goes through the same copy and tile scatter as the

@@ -10,8 +10,11 @@ from raytracing_amd import Context, Scene, render_params, scenes
 W, H = int(os.environ.get("PROBE_W", "3840")), int(os.environ.get("PROBE_H", "2160"))
 which = os.environ.get("PROBE_SCENE", "1000000")
 objects = scenes.default_scene() if which == "teapot" else scenes.soup(int(which), 0x5EED0001)
+import time
 ctx = Context(0)
+t0 = time.time()
 scene = Scene(ctx, objects)
+t_build = time.time() - t0
 p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=scenes.SUN_T0)
 frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
 st = scene.render_device_stats(p, frame.data_ptr())
@@ -31,7 +34,7 @@ ph = [np.mean([ms(e[k], e[k + 1]) for e in evs]) for k in range(4)]
 waves = st["primary_rays"] / 64
 sw = (st["rays"] - st["primary_rays"]) / 64
 label = sys.argv[1] if len(sys.argv) > 1 else ""
-print(f"{label:28s} total {sum(ph):6.2f} ms  cam {ph[0]:5.2f} sort {ph[1]:5.2f} shd {ph[2]:5.2f} res {ph[3]:5.2f} | "
+print(f"{label:28s} build {t_build:6.2f} s  total {sum(ph):6.2f} ms  cam {ph[0]:5.2f} sort {ph[1]:5.2f} shd {ph[2]:5.2f} res {ph[3]:5.2f} | "
       f"cam/wave: nodes {st['primary_node_visits']/waves:6.1f} box {st['primary_box_tests']/waves:7.1f} "
       f"tri/ray {st['primary_tri_tests']/st['primary_rays']:6.2f} KB {st['primary_fetch_bytes']/waves/1024:6.1f} | "
       f"shd/wave: nodes {(st['node_visits']-st['primary_node_visits'])/sw:6.1f} box {(st['box_tests']-st['primary_box_tests'])/sw:7.1f} "
