@@ -165,10 +165,9 @@ __device__ __forceinline__ bool node_step(const SceneView& sv, uint32_t cur, rt_
 // t = q * (scale * inv) + (origin * inv - o * inv): one conversion and one fused multiply-add each.
 #define RT_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu))   // one v_cvt_f32_ubyteK
 template <bool STATS, class Stack>
-__device__ __forceinline__ bool node_step_q(const SceneView& sv, uint32_t cur, rt_f3 inv, float nox, float noy, float noz,
-                                            float closest, Stack& stk, LaneStats& st, uint32_t* next) {
-    const float4* np = sv.qnodes + 4 * (size_t)cur;
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+__device__ __forceinline__ bool node_step_q(const float4 q0, const float4 q1, const float4 q2, const float4 q3, rt_f3 inv,
+                                            float nox, float noy, float noz, float closest, Stack& stk, LaneStats& st,
+                                            uint32_t* next) {
     if (STATS) {
         st.node += 1;
         st.box += 4;
@@ -205,6 +204,12 @@ __device__ __forceinline__ bool node_step_q(const SceneView& sv, uint32_t cur, r
     if (k1 < RT_INF) stk.push(c1, k1);
     *next = c0;
     return k0 < RT_INF;
+}
+template <bool STATS, class Stack>
+__device__ __forceinline__ bool node_step_q(const SceneView& sv, uint32_t cur, rt_f3 inv, float nox, float noy, float noz,
+                                            float closest, Stack& stk, LaneStats& st, uint32_t* next) {
+    const float4* np = sv.qnodes + 4 * (size_t)cur;
+    return node_step_q<STATS>(np[0], np[1], np[2], np[3], inv, nox, noy, noz, closest, stk, st, next);
 }
 
 // One triangle record for one ray. Shadow mode returns true if it occludes.
@@ -1115,6 +1120,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #ifndef RT_CHUNK
 #define RT_CHUNK 64
 #endif
+#ifndef RT_WALK_FUSED
+#define RT_WALK_FUSED 1
+#endif
+#ifndef RT_WALK_REPS
+#define RT_WALK_REPS 4
+#endif
+#ifndef RT_WALK_PIN_LOADS
+#define RT_WALK_PIN_LOADS 1
+#endif
 #ifndef RT_WALK_VOTE
 #define RT_WALK_VOTE 1
 #endif
@@ -1236,7 +1250,14 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             continue;
         }
         bool emitted = false;
-#if RT_WALK_VOTE
+#if RT_WALK_FUSED
+        // The object step runs once RT_VOTE_T lanes wait for it (it is what frees lanes for new rays) or
+        // nothing else can; in every other turn all walking lanes take their step, node or triangle, on
+        // one set of loads (see below).
+        const int n_t = __builtin_popcountll(__ballot(has && !walking));
+        const bool run_t = n_t >= RT_VOTE_T || __ballot(has && walking) == 0ull;
+        const bool run_n = !run_t, run_l = !run_t;
+#elif RT_WALK_VOTE
         // One kind of step per turn: a turn that runs the object step, the node step and the leaf
         // step one after the other keeps every lane idle through two of them. The object step runs
         // once RT_VOTE_T lanes wait for it (it is what frees lanes for new rays) or nothing else
@@ -1290,7 +1311,11 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             if (oi < sv.n_objs) {
                 in_obj = true;
                 const uint32_t root = sv.objs[oi].root;
+#ifdef RT_DBG_NOWALK
+                if (root != EMPTY && !Source::QUEUES) {
+#else
                 if (root != EMPTY) {
+#endif
                     walking = true;
                     cur = root;
                     local_best = 0;
@@ -1306,6 +1331,57 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
         if constexpr (Source::QUEUES) {
             if (__ballot(emitted) != 0ull) src.flush(lane, false);
         }
+#if RT_WALK_FUSED
+#pragma unroll
+        for (int rep = 0; rep < RT_WALK_REPS; ++rep)
+        if (has && walking && run_n) {
+            // A lane at a node reads the node's 64 bytes, a lane at a leaf the 48 bytes of the leaf's next
+            // triangle: the same three or four loads from an address of the lane's own, issued together,
+            // so a turn waits for memory once whatever mix of lanes it holds (a wave that alternates node
+            // turns and leaf turns waits twice, with the lanes of the other kind idle each time). A leaf
+            // reference counts down in place: one record further, one triangle fewer.
+            const bool at_leaf = (cur & LEAF_BIT) != 0u;
+            const float4* ptr = at_leaf ? sv.recs + 3 * (size_t)((cur & 0x7FFFFFFFu) >> 3) : sv.qnodes + 4 * (size_t)cur;
+            // (A leaf lane's fourth load reads into the next record; the array is padded for it. Asked for by
+            // all lanes and pinned here, the four loads go out back to back before either kind computes.)
+            float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
+#if RT_WALK_PIN_LOADS
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                              "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+#endif
+            bool need_pop = true;
+            if (!at_leaf) {
+                uint32_t next;
+                const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
+                if (node_step_q<STATS>(q0, q1, q2, q3, inv, nox, noy, noz, closest, stk, st, &next)) {
+                    cur = next;
+                    need_pop = false;
+                }
+            } else {
+                if (STATS) st.tri += 1, st.bytes += 48;
+                if (record_test<ANY>(q0, q1, q2, oi, o, d, closest, local_best, hit)) {
+                    hit.tri = 0;
+                    stk.sp = 0;
+                    in_obj = false;
+                    oi = sv.n_objs;
+                } else if ((cur & 7u) != 0u) {
+                    cur += 7u;
+                    need_pop = false;
+                }
+            }
+            if (need_pop) {
+                walking = false;
+                while (stk.sp != 0) {
+                    const uint2 e = stk.pop();
+                    if (!(__uint_as_float(e.y) > closest)) {
+                        cur = e.x;
+                        walking = true;
+                        break;
+                    }
+                }
+            }
+        }
+#else
         if (has && walking && ((cur & LEAF_BIT) ? run_l : run_n)) {
             bool need_pop = true;
             if (!(cur & LEAF_BIT)) {
@@ -1344,6 +1420,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                 }
             }
         }
+#endif
     }
     if constexpr (Source::QUEUES) src.flush(lane, true);
 }
@@ -3868,12 +3945,12 @@ struct TreeSource {
         const uint32_t j = level ? queue[idx] : idx;
         const uint32_t slot = j / tr.branches, k = j % tr.branches;
         const uint32_t ps = state[slot];
+        const float4 a = samp[slot];   // read beside the state word, not after it: a refill waits for memory once less
         if (level == 0) {
             if (!(ps & RT_ST_HIT)) return none(j);
             if (k >= tr.scatt && !(sv.objs[ps >> 8].reflectivity > 0.0f)) return none(j);
         }
         const SlotMap sm(p, tile_list, slot);
-        const float4 a = samp[slot];
         const rt_f3 normal = ld3(sv.tri_data + 6 * (size_t)__float_as_uint(a.w));
         o = f3(a.x, a.y, a.z);
         if (k < tr.scatt) {
