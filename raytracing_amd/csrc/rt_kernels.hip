@@ -160,8 +160,8 @@ __device__ __forceinline__ bool node_step(const SceneView& sv, uint32_t cur, rt_
 // holds its own box corner `origin` and a step `scale` per axis, and every child box as six bytes:
 // lo = origin + q_lo * scale, hi = origin + q_hi * scale, rounded outwards by k_quantize_nodes with a
 // margin that covers the roundings below. Layout, four float4:
-//   0: origin.xyz scale.x   1: scale.yz ref0 ref1   2: ref2 ref3 bytes[0..7]   3: bytes[8..23]
-// bytes[6 k .. 6 k + 5] = lo.x lo.y lo.z hi.x hi.y hi.z of child k. The slab distances come out as
+//   0: origin.xyz scale.x   1: scale.yz ref0 ref1   2: ref2 ref3 lo.x hi.x   3: lo.y hi.y lo.z hi.z
+// where each of the last six words holds that plane of the four children, child k in byte k. The slab distances come out as
 // t = q * (scale * inv) + (origin * inv - o * inv): one conversion and one fused multiply-add each.
 #define RT_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu))   // one v_cvt_f32_ubyteK
 template <bool STATS, class Stack>
@@ -177,28 +177,39 @@ __device__ __forceinline__ bool node_step_q(const float4 q0, const float4 q1, co
     const float ox = __builtin_fmaf(q0.x, inv.x, nox), oy = __builtin_fmaf(q0.y, inv.y, noy), oz = __builtin_fmaf(q0.z, inv.z, noz);
     uint32_t c0 = __float_as_uint(q1.z), c1 = __float_as_uint(q1.w);
     uint32_t c2 = __float_as_uint(q2.x), c3 = __float_as_uint(q2.y);
-    const uint32_t w0 = __float_as_uint(q2.z), w1 = __float_as_uint(q2.w), w2 = __float_as_uint(q3.x);
-    const uint32_t w3 = __float_as_uint(q3.y), w4 = __float_as_uint(q3.z), w5 = __float_as_uint(q3.w);
+    // The ray enters a slab through its low plane when it runs upwards along the axis and through its
+    // high plane otherwise: choosing the word of entry planes per axis here (one select each way) saves
+    // the minimum and maximum of every pair of slab distances (two operations per child and axis).
+    // Where the sign cannot tell (a slab distance that is NaN: 0 * inf), maxima and minima skip the NaN
+    // as they did, which keeps the child.
+    const bool upx = !__builtin_signbit(inv.x), upy = !__builtin_signbit(inv.y), upz = !__builtin_signbit(inv.z);
+    const uint32_t xl = __float_as_uint(q2.z), xh = __float_as_uint(q2.w), yl = __float_as_uint(q3.x);
+    const uint32_t yh = __float_as_uint(q3.y), zl = __float_as_uint(q3.z), zh = __float_as_uint(q3.w);
+    const uint32_t nx = upx ? xl : xh, fx = upx ? xh : xl;
+    const uint32_t ny = upy ? yl : yh, fy = upy ? yh : yl;
+    const uint32_t nz = upz ? zl : zh, fz = upz ? zh : zl;
     float k0, k1, k2, k3;
-#define RT_QBOX(K, C, LX, LY, LZ, HX, HY, HZ)                                                        \
-    {                                                                                                \
-        float ax = __builtin_fmaf(LX, sx, ox), bx = __builtin_fmaf(HX, sx, ox);                      \
-        float ay = __builtin_fmaf(LY, sy, oy), by = __builtin_fmaf(HY, sy, oy);                      \
-        float az = __builtin_fmaf(LZ, sz, oz), bz = __builtin_fmaf(HZ, sz, oz);                      \
-        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));           \
-        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));        \
-        K = ((C) != EMPTY && tn <= tf) ? tn : RT_INF;                                                \
+#define RT_QBOX(K, C, B)                                                                              \
+    {                                                                                                 \
+        const float ax = __builtin_fmaf(RT_UB(nx, B), sx, ox), bx = __builtin_fmaf(RT_UB(fx, B), sx, ox);  \
+        const float ay = __builtin_fmaf(RT_UB(ny, B), sy, oy), by = __builtin_fmaf(RT_UB(fy, B), sy, oy);  \
+        const float az = __builtin_fmaf(RT_UB(nz, B), sz, oz), bz = __builtin_fmaf(RT_UB(fz, B), sz, oz);  \
+        const float tn = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.0f));                                       \
+        const float tf = fminf(fminf(bx, by), fminf(bz, closest));                                    \
+        K = ((C) != EMPTY && tn <= tf) ? tn : RT_INF;                                                 \
     }
-    RT_QBOX(k0, c0, RT_UB(w0, 0), RT_UB(w0, 1), RT_UB(w0, 2), RT_UB(w0, 3), RT_UB(w1, 0), RT_UB(w1, 1))
-    RT_QBOX(k1, c1, RT_UB(w1, 2), RT_UB(w1, 3), RT_UB(w2, 0), RT_UB(w2, 1), RT_UB(w2, 2), RT_UB(w2, 3))
-    RT_QBOX(k2, c2, RT_UB(w3, 0), RT_UB(w3, 1), RT_UB(w3, 2), RT_UB(w3, 3), RT_UB(w4, 0), RT_UB(w4, 1))
-    RT_QBOX(k3, c3, RT_UB(w4, 2), RT_UB(w4, 3), RT_UB(w5, 0), RT_UB(w5, 1), RT_UB(w5, 2), RT_UB(w5, 3))
+    RT_QBOX(k0, c0, 0)
+    RT_QBOX(k1, c1, 1)
+    RT_QBOX(k2, c2, 2)
+    RT_QBOX(k3, c3, 3)
 #undef RT_QBOX
     RT_CSWAP(k0, k1, c0, c1)
     RT_CSWAP(k2, k3, c2, c3)
     RT_CSWAP(k0, k2, c0, c2)
+#if !RT_WALK_HALF_SORT
     RT_CSWAP(k1, k3, c1, c3)
     RT_CSWAP(k1, k2, c1, c2)
+#endif
     if (k3 < RT_INF) stk.push(c3, k3);
     if (k2 < RT_INF) stk.push(c2, k2);
     if (k1 < RT_INF) stk.push(c1, k1);
@@ -1094,11 +1105,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // The walk of closest_all is kept as a per-lane state machine: `walking` lanes take one node or one
 // leaf per turn; the others move to the next object whose box their ray meets (after the trailing
 // triangles of the one they leave), or deliver their result and become idle. A wave takes ray
-// indices RT_CHUNK at a time and hands them to its idle lanes RT_REFILL or more at a time. Most
-// chunks are the wave's own by number (wave w owns chunks w, w + waves, ...), the last
-// 2^-RT_DYNAMIC_SHIFT of the rays are handed out through a global counter so that the waves end
-// together: an atomic on one address shared by the whole device takes about 12 ns, which would
-// bound a launch of cheap rays if every chunk went through it. The loop ends when the wave has had
+// indices RT_CHUNK at a time and hands them to its idle lanes RT_REFILL or more at a time. The
+// chunks of the first RT_STATIC_PCT per cent of the rays are the wave's own by number (wave w owns
+// chunks w, w + waves, ...), the rest are handed out through a global counter so that the waves end
+// together. The waves of a launch do not run at one speed: a SIMD issues from its oldest waves first,
+// and with eight waves on it the youngest gets about half the instructions of the oldest (measured
+// with the clock inside the kernel: equal shares of a launch ended between 98 and 127 ms), so the
+// shared part has to be large. It cannot be everything: an atomic on one address shared by the whole
+// device takes about 12 ns, which would bound a launch of cheap rays, and the diffuse-bounce frame
+// measured 148 / 134 / 133 / 137 / 149 ms with 0 / 35 / 42 / 50 / 75 per cent given out by number.
+// The loop ends when the wave has had
 // its own chunks, the counter has passed the last ray and no lane holds one. Every wave overshoots
 // the counter by at most one chunk, so n_rays must stay RT_WALK_HEADROOM below 2^32.
 // Source: bool init(j, o, d) gives ray j (false: there is none, and the source has stored whatever
@@ -1126,6 +1142,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #ifndef RT_WALK_REPS
 #define RT_WALK_REPS 4
 #endif
+#ifndef RT_WALK_HALF_SORT
+#define RT_WALK_HALF_SORT 0
+#endif
 #ifndef RT_WALK_PIN_LOADS
 #define RT_WALK_PIN_LOADS 1
 #endif
@@ -1141,8 +1160,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #ifndef RT_VOTE_LEAF_WEIGHT
 #define RT_VOTE_LEAF_WEIGHT 2
 #endif
-#ifndef RT_DYNAMIC_SHIFT
-#define RT_DYNAMIC_SHIFT 2
+#ifndef RT_STATIC_PCT
+#define RT_STATIC_PCT 50
 #endif
 // The persistent walk reads the compact nodes (node_step_q).
 #ifndef RT_WALK_QNODES
@@ -1162,22 +1181,31 @@ struct WalkLds {
 struct WalkStack {
     WalkLds* lds;    // the wave's block (wave-uniform); entry e of this lane at [e * 64 + threadIdx.x]
     uint2* spill;    // RT_STACK_MAX - RT_WALK_LDS entries of the caller's, in private memory. (An array inside
-                     // this struct would drag sp into private memory with it: every push and pop then
-                     // goes through scratch loads.)
-    int sp;
+                     // this struct would drag the stack pointer into private memory with it: every push and
+                     // pop then goes through scratch loads.)
+    // The stack pointer as the byte offset of the next entry's reference in the wave's block: entries * 256
+    // + 4 * lane. The reference's address is then the pointer itself and the key's half of it, where an
+    // entry count costs a shift, an or and two more shifts per push and per pop.
+    uint32_t spb;
+    __device__ __forceinline__ void reset() { spb = 4u * threadIdx.x; }
+    __device__ __forceinline__ bool empty() const { return spb < 256u; }
     __device__ __forceinline__ void push(uint32_t node, float tnear) {
-        if (sp < RT_WALK_LDS) {
-            lds->refs[sp * 64 + threadIdx.x] = node;
-            lds->keys[sp * 64 + threadIdx.x] = (uint16_t)(__float_as_uint(tnear) >> 16);
-        } else if (sp < RT_STACK_MAX) {
-            spill[sp - RT_WALK_LDS] = make_uint2(node, __float_as_uint(tnear));
+        char* base = reinterpret_cast<char*>(lds);
+        if (spb < RT_WALK_LDS * 256u) {
+            *reinterpret_cast<uint32_t*>(base + spb) = node;
+            *reinterpret_cast<uint16_t*>(base + sizeof(lds->refs) + (spb >> 1)) = (uint16_t)(__float_as_uint(tnear) >> 16);
+        } else if (spb < RT_STACK_MAX * 256u) {
+            spill[(spb >> 8) - RT_WALK_LDS] = make_uint2(node, __float_as_uint(tnear));
         }
-        sp = sp < RT_STACK_MAX ? sp + 1 : sp;
+        spb = spb < RT_STACK_MAX * 256u ? spb + 256u : spb;
     }
     __device__ __forceinline__ uint2 pop() {
-        --sp;
-        if (sp < RT_WALK_LDS) return make_uint2(lds->refs[sp * 64 + threadIdx.x], (uint32_t)lds->keys[sp * 64 + threadIdx.x] << 16);
-        return spill[sp - RT_WALK_LDS];
+        spb -= 256u;
+        char* base = reinterpret_cast<char*>(lds);
+        if (spb < RT_WALK_LDS * 256u)
+            return make_uint2(*reinterpret_cast<const uint32_t*>(base + spb),
+                              (uint32_t)*reinterpret_cast<const uint16_t*>(base + sizeof(lds->refs) + (spb >> 1)) << 16);
+        return spill[(spb >> 8) - RT_WALK_LDS];
     }
 };
 
@@ -1189,12 +1217,12 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
     WalkStack stk;
     stk.spill = stack_rest;
     stk.lds = &s_stack;
-    stk.sp = 0;
+    stk.reset();
     bool has = false, walking = false, in_obj = false;
     bool exhausted = false;  // wave-uniform: the counter has passed the last ray
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: ray indices taken and not yet handed out
-    // Whole rounds of one chunk per wave inside the first (1 - 2^-RT_DYNAMIC_SHIFT) of the rays.
-    const uint32_t static_turns = (n_rays - (n_rays >> RT_DYNAMIC_SHIFT)) / (gridDim.x * (uint32_t)RT_CHUNK);
+    // Whole rounds of one chunk per wave inside the first RT_STATIC_PCT per cent of the rays.
+    const uint32_t static_turns = (uint32_t)((uint64_t)n_rays * RT_STATIC_PCT / 100u) / (gridDim.x * (uint32_t)RT_CHUNK);
     uint32_t turn = 0;
     uint32_t j = 0, oi = 0, cur = 0, local_best = 0;
     rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 1.0f), inv = d;
@@ -1319,7 +1347,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                     walking = true;
                     cur = root;
                     local_best = 0;
-                    stk.sp = 0;
+                    stk.reset();
                 }
             } else {
                 hit.closest = closest;
@@ -1345,9 +1373,12 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             // (A leaf lane's fourth load reads into the next record; the array is padded for it. Asked for by
             // all lanes and pinned here, the four loads go out back to back before either kind computes.)
             float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
-#if RT_WALK_PIN_LOADS
+#if RT_WALK_PIN_LOADS == 1
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
                               "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+#elif RT_WALK_PIN_LOADS == 2
+            asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                              "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
 #endif
             bool need_pop = true;
             if (!at_leaf) {
@@ -1361,7 +1392,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                 if (STATS) st.tri += 1, st.bytes += 48;
                 if (record_test<ANY>(q0, q1, q2, oi, o, d, closest, local_best, hit)) {
                     hit.tri = 0;
-                    stk.sp = 0;
+                    stk.reset();
                     in_obj = false;
                     oi = sv.n_objs;
                 } else if ((cur & 7u) != 0u) {
@@ -1371,10 +1402,10 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             }
             if (need_pop) {
                 walking = false;
-                while (stk.sp != 0) {
+                while (!stk.empty()) {
                     const uint2 e = stk.pop();
+                    cur = e.x;   // (taken before the entry is looked at: the reference is then read beside its key, not after it)
                     if (!(__uint_as_float(e.y) > closest)) {
-                        cur = e.x;
                         walking = true;
                         break;
                     }
@@ -1402,7 +1433,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                 if (leaf_step<ANY, STATS>(sv, cur, oi, o, d, closest, local_best, hit, st)) {
                     // Shadow mode: occluded; the ray is finished (hit.tri != RT_MISS marks it).
                     hit.tri = 0;
-                    stk.sp = 0;
+                    stk.reset();
                     in_obj = false;
                     oi = sv.n_objs;
                 }
@@ -1410,10 +1441,10 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             if (need_pop) {
                 // Next pending node whose entry distance is not beyond the current nearest hit.
                 walking = false;
-                while (stk.sp != 0) {
+                while (!stk.empty()) {
                     const uint2 e = stk.pop();
+                    cur = e.x;   // (taken before the entry is looked at: the reference is then read beside its key, not after it)
                     if (!(__uint_as_float(e.y) > closest)) {
-                        cur = e.x;
                         walking = true;
                         break;
                     }
@@ -1676,8 +1707,8 @@ __global__ void k_quantize_nodes(const rtbvh::Node4* __restrict__ nodes, uint32_
                 // a corner the grid cannot reach (should not happen: 254 steps span the padded box)
                 if (__builtin_fmaf((float)ql, scale[a], origin[a]) > l || __builtin_fmaf((float)qh, scale[a], origin[a]) < h) ql = 0, qh = 255;
             }
-            q[6 * k + a] = (unsigned char)ql;
-            q[6 * k + 3 + a] = (unsigned char)qh;
+            q[8 * a + k] = (unsigned char)ql;       // word 2 a: the low planes of axis a, word 2 a + 1: the high ones
+            q[8 * a + 4 + k] = (unsigned char)qh;
         }
     }
     uint32_t w[6];
@@ -4034,7 +4065,14 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
                          queues + (size_t)level * tr.level_rays,
                          last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
                          last ? nullptr : counts + level + 1, s_q};
+#ifdef RT_DEBUG_CLOCK
+    const long long c0 = clock64(), w0 = wall_clock64();
+#endif
     persistent_walk<false, STATS>(sv, n, counter, src, s_stack, st);
+#ifdef RT_DEBUG_CLOCK
+    if (blockIdx.x % 1024u == 7u && threadIdx.x == 0 && n > 1000000u)
+        printf("k_wf_bounce block %u of %u: start %lld end %lld wall ticks (100 MHz), %lld shader ticks\n", blockIdx.x, gridDim.x, w0 % 100000000ll, wall_clock64() % 100000000ll, clock64() - c0);
+#endif
     if (STATS) flush_stats(st, stats);
 }
 
