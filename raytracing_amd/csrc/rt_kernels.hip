@@ -206,10 +206,8 @@ __device__ __forceinline__ bool node_step_q(const float4 q0, const float4 q1, co
     RT_CSWAP(k0, k1, c0, c1)
     RT_CSWAP(k2, k3, c2, c3)
     RT_CSWAP(k0, k2, c0, c2)
-#if !RT_WALK_HALF_SORT
     RT_CSWAP(k1, k3, c1, c3)
     RT_CSWAP(k1, k2, c1, c2)
-#endif
     if (k3 < RT_INF) stk.push(c3, k3);
     if (k2 < RT_INF) stk.push(c2, k2);
     if (k1 < RT_INF) stk.push(c1, k1);
@@ -1112,8 +1110,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // and with eight waves on it the youngest gets about half the instructions of the oldest (measured
 // with the clock inside the kernel: equal shares of a launch ended between 98 and 127 ms), so the
 // shared part has to be large. It cannot be everything: an atomic on one address shared by the whole
-// device takes about 12 ns, which would bound a launch of cheap rays, and the diffuse-bounce frame
-// measured 148 / 134 / 133 / 137 / 149 ms with 0 / 35 / 42 / 50 / 75 per cent given out by number.
+// device takes about 12 ns, which would bound a launch of cheap rays: the diffuse-bounce frame
+// measured 148 / 134 / 137 / 149 ms with 0 / 35 / 50 / 75 per cent given out by number (30 to 50 per
+// cent are within 1 % of each other).
 // The loop ends when the wave has had
 // its own chunks, the counter has passed the last ray and no lane holds one. Every wave overshoots
 // the counter by at most one chunk, so n_rays must stay RT_WALK_HEADROOM below 2^32.
@@ -1136,38 +1135,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #ifndef RT_CHUNK
 #define RT_CHUNK 64
 #endif
-#ifndef RT_WALK_FUSED
-#define RT_WALK_FUSED 1
-#endif
 #ifndef RT_WALK_REPS
 #define RT_WALK_REPS 4
 #endif
-#ifndef RT_WALK_HALF_SORT
-#define RT_WALK_HALF_SORT 0
-#endif
-#ifndef RT_WALK_PIN_LOADS
-#define RT_WALK_PIN_LOADS 1
-#endif
-#ifndef RT_WALK_VOTE
-#define RT_WALK_VOTE 1
-#endif
 #ifndef RT_VOTE_T
 #define RT_VOTE_T 16
-#endif
-#ifndef RT_VOTE_NODE_WEIGHT
-#define RT_VOTE_NODE_WEIGHT 1
-#endif
-#ifndef RT_VOTE_LEAF_WEIGHT
-#define RT_VOTE_LEAF_WEIGHT 2
 #endif
 #ifndef RT_STATIC_PCT
 #define RT_STATIC_PCT 50
 #endif
 // The persistent walk reads the compact nodes (node_step_q).
-#ifndef RT_WALK_QNODES
-#define RT_WALK_QNODES 1
-#endif
-#define RT_WALK_MAX_GRID 8192u                              // waves of a persistent launch
+#define RT_WALK_MAX_GRID (1024u * RT_WALK_WAVES)                              // waves of a persistent launch
 #define RT_WALK_HEADROOM (RT_WALK_MAX_GRID * RT_CHUNK + 64u)  // counter overshoot at the end of a launch
 // Stack of the persistent walk: RT_WALK_LDS entries of 6 bytes in LDS (node reference, and the
 // entry distance cut to its upper 16 bits: rounded towards zero, so an entry is never dropped that
@@ -1278,29 +1256,11 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             continue;
         }
         bool emitted = false;
-#if RT_WALK_FUSED
         // The object step runs once RT_VOTE_T lanes wait for it (it is what frees lanes for new rays) or
         // nothing else can; in every other turn all walking lanes take their step, node or triangle, on
         // one set of loads (see below).
         const int n_t = __builtin_popcountll(__ballot(has && !walking));
         const bool run_t = n_t >= RT_VOTE_T || __ballot(has && walking) == 0ull;
-        const bool run_n = !run_t, run_l = !run_t;
-#elif RT_WALK_VOTE
-        // One kind of step per turn: a turn that runs the object step, the node step and the leaf
-        // step one after the other keeps every lane idle through two of them. The object step runs
-        // once RT_VOTE_T lanes wait for it (it is what frees lanes for new rays) or nothing else
-        // can; otherwise the leaf step unless the lanes at a node outnumber those at a leaf two to
-        // one (a leaf step is the longer one and lowers `closest`). Measured against all three
-        // steps every turn: +6 % on scatter and mirror rays, the same on random rays.
-        const int n_t = __builtin_popcountll(__ballot(has && !walking));
-        const int n_n = __builtin_popcountll(__ballot(has && walking && !(cur & LEAF_BIT)));
-        const int n_l = __builtin_popcountll(__ballot(has && walking && (cur & LEAF_BIT) != 0u));
-        int phase = (n_n * RT_VOTE_NODE_WEIGHT >= n_l * RT_VOTE_LEAF_WEIGHT) ? 1 : 2;
-        if (n_t >= RT_VOTE_T || (n_n == 0 && n_l == 0)) phase = 0;
-        const bool run_t = phase == 0, run_n = phase == 1, run_l = phase == 2;
-#else
-        const bool run_t = true, run_n = true, run_l = true;
-#endif
         if (run_t && has && !walking) {
             // Leave the current object (its trailing n % 8 triangles, src/main.rs:157-169: scalar
             // arithmetic, `closest` is not lowered, the last qualifying one wins), then find the
@@ -1339,11 +1299,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             if (oi < sv.n_objs) {
                 in_obj = true;
                 const uint32_t root = sv.objs[oi].root;
-#ifdef RT_DBG_NOWALK
-                if (root != EMPTY && !Source::QUEUES) {
-#else
                 if (root != EMPTY) {
-#endif
                     walking = true;
                     cur = root;
                     local_best = 0;
@@ -1359,10 +1315,12 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
         if constexpr (Source::QUEUES) {
             if (__ballot(emitted) != 0ull) src.flush(lane, false);
         }
-#if RT_WALK_FUSED
+        // RT_WALK_REPS such steps per turn of the refill and object logic above: the walk is bound by
+        // instruction issue, and that logic costs every lane its ballots and branches whether it has
+        // anything to do there or not.
 #pragma unroll
         for (int rep = 0; rep < RT_WALK_REPS; ++rep)
-        if (has && walking && run_n) {
+        if (has && walking && !run_t) {
             // A lane at a node reads the node's 64 bytes, a lane at a leaf the 48 bytes of the leaf's next
             // triangle: the same three or four loads from an address of the lane's own, issued together,
             // so a turn waits for memory once whatever mix of lanes it holds (a wave that alternates node
@@ -1373,13 +1331,8 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             // (A leaf lane's fourth load reads into the next record; the array is padded for it. Asked for by
             // all lanes and pinned here, the four loads go out back to back before either kind computes.)
             float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
-#if RT_WALK_PIN_LOADS == 1
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
                               "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
-#elif RT_WALK_PIN_LOADS == 2
-            asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
-                              "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
-#endif
             bool need_pop = true;
             if (!at_leaf) {
                 uint32_t next;
@@ -1412,46 +1365,6 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                 }
             }
         }
-#else
-        if (has && walking && ((cur & LEAF_BIT) ? run_l : run_n)) {
-            bool need_pop = true;
-            if (!(cur & LEAF_BIT)) {
-                uint32_t next;
-                // -(o * inv) is worked out here rather than kept per ray: three registers fewer to hold
-                // through the whole walk (they were spilled), for three multiplications per step.
-                const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
-#if RT_WALK_QNODES
-                const bool go = node_step_q<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next);
-#else
-                const bool go = node_step<STATS>(sv, cur, inv, nox, noy, noz, closest, stk, st, &next);
-#endif
-                if (go) {
-                    cur = next;
-                    need_pop = false;
-                }
-            } else {
-                if (leaf_step<ANY, STATS>(sv, cur, oi, o, d, closest, local_best, hit, st)) {
-                    // Shadow mode: occluded; the ray is finished (hit.tri != RT_MISS marks it).
-                    hit.tri = 0;
-                    stk.reset();
-                    in_obj = false;
-                    oi = sv.n_objs;
-                }
-            }
-            if (need_pop) {
-                // Next pending node whose entry distance is not beyond the current nearest hit.
-                walking = false;
-                while (!stk.empty()) {
-                    const uint2 e = stk.pop();
-                    cur = e.x;   // (taken before the entry is looked at: the reference is then read beside its key, not after it)
-                    if (!(__uint_as_float(e.y) > closest)) {
-                        walking = true;
-                        break;
-                    }
-                }
-            }
-        }
-#endif
     }
     if constexpr (Source::QUEUES) src.flush(lane, true);
 }
