@@ -190,6 +190,25 @@ def config5_leg(ctx, args, rank, world, comm, dist, red_dev, scene=None):
             "rays_per_frame": int(rays.item()), "n_gpus": world}
 
 
+TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
+TRAFFIC_NAMES = {"k_shadow_cells": "k_shadow_cells<false, true>", "k_raster_tile": "k_raster_tile<false>",
+                 "k_wf_shadow": "k_wf_shadow<false>", "k_wf_bounce": "k_wf_bounce<false>"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the counter passes kept with the repository, or null."""
+    out = {"traffic": None, "traffic_profile": TRAFFIC_PROFILE + " (rocprofv3 --pmc passes of this command, tools/measure.sh)"}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_PROFILE)) as f:
+            k = json.load(f)["kernels"].get(TRAFFIC_NAMES.get(kernel, kernel))
+        if k:
+            out["traffic"] = k["bytes_per_launch"]
+            out["traffic_fetch_doubled"] = k["bytes_per_launch_fetch_doubled"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 def bounce_roofline(ctx, args, new_event, elapsed_ms, scene):
     """A short run of the diffuse-bounce workload (config 4: soup-10M, 3840x2160, four samples, ten
     scatter rays off every hit and the shadow rays of all of them): frame time, and the roofline
@@ -245,7 +264,7 @@ def bounce_roofline(ctx, args, new_event, elapsed_ms, scene):
         "peak": HBM_PEAK / 1e9,
         "unit": "GB/s",
         "frac": alg_bytes / sec / HBM_PEAK,
-        "traffic": None,
+        **pmc_traffic("k_wf_bounce"),
         "alg_bytes_per_launch": alg_bytes,
         "alg_bytes_parts": {"samples": 20 * samples, "ray_slots": 24 * slots, "nodes4_compact": nodes_compact, "recs": sizes["recs"],
                             "tri_data": sizes["tri_data"]},
@@ -512,10 +531,11 @@ def main():
             return {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                # HBM traffic needs hardware counters (rocprofv3 --pmc passes of this very command): not
-                # measured inside this process. The kept summaries are under profiles/.
-                "traffic": None,
-                "traffic_profile": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)",
+                # HBM traffic needs hardware counters (rocprofv3 --pmc passes of this very command, one
+                # pass per counter block: tools/measure.sh): not measurable inside this process. The
+                # figure is the one kept under profiles/ for this build (bytes per launch, FETCH_SIZE +
+                # WRITE_SIZE as reported; the file also holds the upper bound with the fetch doubled).
+                **pmc_traffic(kernel),
                 "kernel_ms": kernel_ms, "launch_unit": unit, "units_per_launch": units,
                 "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_unit": alg_bytes / max(1, units),
                 "alg_bytes_parts": alg_parts,
