@@ -514,8 +514,16 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         cells = lp.uscale > 0.0f && lp.vscale > 0.0f && lp.key_bits <= 18 && s->objects.size() <= 32 &&
                 s->n_tris_total > 0 && s->n_tris_total < (1u << 26) && opt.shadow != 'w' &&
                 (force || (s->n_tris_total >= 32768 && mean_list <= 1.4 * (double)mean_limit));   // the estimate runs 1.4 x high on the soups
-        // Room per cell: 512 entries at 2^16 cells (24 bytes each: 805 MB), 1024 when forced; 256 at 2^18.
-        lc_cap_shift = lp.key_bits <= 16 ? (force ? 10u : 9u) : 8u;
+        // Room per cell, 24 bytes an entry: the power of two from three times the estimated mean list up
+        // (the longest list of the soups is about twice their mean; a scene that is denser than that in
+        // places overflows a list and takes the tree walk), between 64 and 512 entries at 2^16 cells
+        // (50 to 805 MB), 1024 when forced; at most 256 at 2^18.
+        {
+            const uint32_t top = lp.key_bits <= 16 ? (force ? 10u : 9u) : 8u;
+            lc_cap_shift = 6u;
+            while (lc_cap_shift < top && (double)(1u << lc_cap_shift) < 3.0 * mean_list) ++lc_cap_shift;
+            if (force) lc_cap_shift = top;
+        }
         if (cells) {
             if (w.lc_cells < lc_cells) {
                 if (w.lc_counts) (void)hipFree(w.lc_counts);
@@ -526,14 +534,11 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
             }
             const size_t want = lc_cells << lc_cap_shift;
             if (w.lc_capacity < want) {
-                if (w.lc_boxes) (void)hipFree(w.lc_boxes);
-                if (w.lc_ids) (void)hipFree(w.lc_ids);
-                w.lc_boxes = nullptr;
-                w.lc_ids = nullptr;
+                if (w.lc_lists) (void)hipFree(w.lc_lists);
+                w.lc_lists = nullptr;
                 w.lc_capacity = 0;
                 // the lists are read four entries at a time: room for a read that starts at the last one
-                HIP_TRY(hipMalloc((void**)&w.lc_boxes, (want + 4) * sizeof(float4)));
-                HIP_TRY(hipMalloc((void**)&w.lc_ids, (want + 4) * 8));   // id and depth
+                HIP_TRY(hipMalloc((void**)&w.lc_lists, (want + 4) * 24));   // patch, id, depth
                 w.lc_capacity = want;
             }
             if (!w.lc_flags) HIP_TRY(hipMalloc((void**)&w.lc_flags, 256));
@@ -552,7 +557,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         // After whatever used this set's lists last (the same stream `ws`, a frame or two ago).
         HIP_TRY(hipEventRecord(s->side_fork[set], ws));
         HIP_TRY(hipStreamWaitEvent(s->side_stream[set], s->side_fork[set], 0));
-        HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, lc_mean,
+        HIP_TRY(rtk::lcell_lists(s->view, dp, lp, s->n_tris_total, w.lc_counts, w.lc_lists, lc_cap_shift, lc_mean,
                                  w.lc_flags, w.keys[0], opt.cells_redo_all, s->side_stream[set]));
         HIP_TRY(hipEventRecord(s->side_done[set], s->side_stream[set]));
         return RT_OK;
@@ -658,7 +663,7 @@ int render_common(rt_scene* s, const rt_render_params* p, uint8_t* d_rgba8, uint
         if (cells) {
             HIP_TRY(hipStreamWaitEvent(ws, s->side_done[set], 0));
             HIP_TRY(rtk::shadow_cells(s->view, dp, lp, (uint32_t)n_slots, w.keys[1], w.order, w.samp, w.state, d_stats,
-                                      w.n_valid, w.lc_counts, w.lc_boxes, w.lc_ids, lc_cap_shift, w.lc_flags, w.keys[0], ws));   // the sort is done with its input keys
+                                      w.n_valid, w.lc_counts, w.lc_lists, lc_cap_shift, w.lc_flags, w.keys[0], ws));   // the sort is done with its input keys
         }
         HIP_TRY(rtk::wf_shadow(s->view, dp, (uint32_t)n_slots, lp.key_bits > 16 ? lp.key_bits - 16 : 0u, w.keys[1],
                                w.order, w.samp, w.state, d_stats, ws, own_sort ? w.n_valid : nullptr,

@@ -112,18 +112,17 @@ struct FrameWork {
     size_t temp_bytes = 0;
     void* radix_work = nullptr;      // workspace of the library's own sort (rtk::radix_sort_valid)
     uint32_t* n_valid = nullptr;     // device word: shadow rays among the sorted keys
-    // Shadow rays by light-space cells: triangles per cell, the lists (a box and an id per entry, the
-    // same room for every cell), and the device words that say whether the lists are usable.
+    // Shadow rays by light-space cells: triangles per cell, the lists (24 bytes an entry: patch, id and
+    // depth; the same room for every cell), and the device words that say whether the lists are usable.
     uint32_t* lc_counts = nullptr;
     size_t lc_cells = 0;
-    float4* lc_boxes = nullptr;
-    uint32_t* lc_ids = nullptr;
+    float* lc_lists = nullptr;
     size_t lc_capacity = 0;
     uint32_t* lc_flags = nullptr;
     void release() {
         for (void* q : {(void*)samp, (void*)state, (void*)keys[0], (void*)keys[1], (void*)order, (void*)counts, (void*)zbuf, (void*)cam_table, temp,
                         (void*)bin_counts, (void*)bin_offsets, (void*)bin_list, (void*)bin_recs, radix_work, (void*)n_valid,
-                        (void*)lc_counts, (void*)lc_boxes, (void*)lc_ids, (void*)lc_flags})
+                        (void*)lc_counts, (void*)lc_lists, (void*)lc_flags})
             if (q) (void)hipFree(q);
         *this = FrameWork();
     }

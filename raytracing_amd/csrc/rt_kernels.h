@@ -61,7 +61,7 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
                      const uint32_t* d_done_flag = nullptr);
 // Shadow rays by light-space cells (k_lcell_bin, k_lcell_check, k_shadow_cells). lcell_lists builds
 // the per-cell triangle lists for the grid of lp's key: 2^key_bits cells with room for 2^cap_shift entries
-// each (d_counts: one word per cell; d_boxes, d_ids: cells << cap_shift entries and four more), and leaves
+// each (d_counts: one word per cell; d_lists: cells << cap_shift entries of six words and four more), and leaves
 // d_flags[0] = 1 when every list fits its room and the lists of the cells that have one average at most
 // max_mean entries; d_flags[1..3] = the lists' total, the longest, the cells with a list (d_flags: 64
 // words; from word 16 on what shadow_cells needs at its end: the leaf boxes and d_redo). redo_all (tests): every ray the lists find
@@ -70,12 +70,12 @@ hipError_t wf_shadow(const SceneView& sv, const DevRenderParams& p, uint32_t n, 
 // (the slots of the rays whose occluder fails the reference's leaf test, counted in d_flags[5]; a second
 // kernel of the same call runs the reference's own search for them).
 hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
-                       uint32_t* d_counts, float4* d_boxes, uint32_t* d_ids, uint32_t cap_shift, uint32_t max_mean,
+                       uint32_t* d_counts, float* d_lists, uint32_t cap_shift, uint32_t max_mean,
                        uint32_t* d_flags, uint32_t* d_redo, bool redo_all, hipStream_t s);
 hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
                         const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float4* d_boxes,
-                        const uint32_t* d_ids, uint32_t cap_shift, uint32_t* d_flags, uint32_t* d_redo, hipStream_t s);
+                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float* d_lists,
+                        uint32_t cap_shift, uint32_t* d_flags, uint32_t* d_redo, hipStream_t s);
 hipError_t wf_resolve(const SceneView& sv, const DevRenderParams& p, const uint32_t* d_tile_list, const float4* d_samp,
                       const uint32_t* d_state, uint8_t* d_rgba8, uint32_t* d_hit_ids, hipStream_t s);
 // Diffuse and mirror bounces as a pipeline: one launch of wf_bounce per level of the tree of

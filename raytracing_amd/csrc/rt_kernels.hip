@@ -3328,13 +3328,12 @@ struct LightCells {
 __device__ __forceinline__ uint32_t lcell_of(uint32_t cx, uint32_t cy) { return spread16(cx) | (spread16(cy) << 1); }
 
 // One thread per triangle: for every cell its patch touches, counts[cell] += 1 and, while the cell's
-// list (room for `1 << cap_shift` entries at cell << cap_shift) has room, the patch (boxes) and the id
-// and object with the entry's depth (ids, two words an entry) go into it. counts keeps counting past
-// the room, so that k_lcell_check sees it.
+// list (room for `1 << cap_shift` entries at cell << cap_shift) has room, an entry goes into it: six
+// words, the patch (x0, y0, width, height), the id with the object's index above it, and the entry's
+// depth. counts keeps counting past the room, so that k_lcell_check sees it.
 __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams p, LightProj lp, LightCells lc,
                                                    uint32_t n_tris_total, uint32_t* __restrict__ counts,
-                                                   float4* __restrict__ boxes, uint32_t* __restrict__ ids,
-                                                   uint32_t cap_shift) {
+                                                   float* __restrict__ lists, uint32_t cap_shift) {
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
     if (id >= n_tris_total) return;
     uint32_t moi = 0;
@@ -3411,9 +3410,11 @@ __global__ __launch_bounds__(256) void k_lcell_bin(SceneView sv, DevRenderParams
             const uint32_t cell = lcell_of(cx, cy);
             const uint32_t k = atomicAdd(&counts[cell], 1u);
             if (k < (1u << cap_shift)) {
-                const size_t pos = ((size_t)cell << cap_shift) + k;
-                boxes[pos] = make_float4(x0, y0, bw, bh);
-                reinterpret_cast<uint2*>(ids)[pos] = make_uint2(id | (moi << RT_LCELL_ID_BITS), __float_as_uint(zcull));
+                // one record of 24 bytes (8-byte aligned): three stores into one or two 32-byte sectors
+                float2* rec = reinterpret_cast<float2*>(lists + 6 * (((size_t)cell << cap_shift) + k));
+                rec[0] = make_float2(x0, y0);
+                rec[1] = make_float2(bw, bh);
+                rec[2] = make_float2(__uint_as_float(id | (moi << RT_LCELL_ID_BITS)), zcull);
             }
         }
 }
@@ -3503,8 +3504,7 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
                                                         DevStats* __restrict__ stats,
                                                         const uint32_t* __restrict__ n_valid,
                                                         const uint32_t* __restrict__ counts,
-                                                        const float4* __restrict__ boxes,
-                                                        const uint32_t* __restrict__ ids, uint32_t cap_shift,
+                                                        const float* __restrict__ lists, uint32_t cap_shift,
                                                         uint32_t* __restrict__ flags) {
     __shared__ ShadowCellsLds lds;
     if (flags[0] == 0u) return;
@@ -3606,12 +3606,13 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
             if (qu != qu) quc = nan;
         }
     };
+    // four entries of six words: sixteen words and eight more
     auto four = [&](const f32x16_t& B, const f32x8_t& E, uint32_t cnt) {
         if (STATS && quc == quc) st.box += cnt;
-        entry(B[0], B[1], B[2], B[3], __float_as_uint(E[0]), E[1]);
-        if (cnt > 1u) entry(B[4], B[5], B[6], B[7], __float_as_uint(E[2]), E[3]);
-        if (cnt > 2u) entry(B[8], B[9], B[10], B[11], __float_as_uint(E[4]), E[5]);
-        if (cnt > 3u) entry(B[12], B[13], B[14], B[15], __float_as_uint(E[6]), E[7]);
+        entry(B[0], B[1], B[2], B[3], __float_as_uint(B[4]), B[5]);
+        if (cnt > 1u) entry(B[6], B[7], B[8], B[9], __float_as_uint(B[10]), B[11]);
+        if (cnt > 2u) entry(B[12], B[13], B[14], B[15], __float_as_uint(E[0]), E[1]);
+        if (cnt > 3u) entry(E[2], E[3], E[4], E[5], __float_as_uint(E[6]), E[7]);
     };
     unsigned long long todo = alive;
     while (todo != 0ull) {
@@ -3621,22 +3622,22 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
         todo &= ~grp;
         quc = mine ? qu : nan;
         const uint32_t beg = c << cap_shift, end = beg + sload1u(counts + c);
-        // The lists are read four entries at a time through the scalar cache (a box is x0, y0, x1 - x0,
-        // y1 - y0; an id comes with its entry's depth), the next four while the present four are worked on: the address of the next read
+        // The lists are read four entries at a time through the scalar cache (an entry is x0, y0, x1 - x0,
+        // y1 - y0, id, depth), the next four while the present four are worked on: the address of the next read
         // is made to depend on the present data (a width's sign bit, always clear), which keeps the
         // compiler from issuing it ahead of the wait for that data and then waiting for both.
         if (beg == end) continue;
-        f32x16_t B0 = sload16(boxes + beg), B1 = B0;
-        f32x8_t E0 = sload8(ids + 2 * (size_t)beg), E1 = E0;
+        f32x16_t B0 = sload16(lists + 6 * (size_t)beg), B1 = B0;
+        f32x8_t E0 = sload8(lists + 6 * (size_t)beg + 16), E1 = E0;
         for (uint32_t j = beg;;) {
             if ((alive & grp) == 0ull) break;
             uint32_t nx = j + 4u + (__float_as_uint(B0[2]) >> 31);
-            if (nx < end) B1 = sload16(boxes + nx), E1 = sload8(ids + 2 * (size_t)nx);
+            if (nx < end) B1 = sload16(lists + 6 * (size_t)nx), E1 = sload8(lists + 6 * (size_t)nx + 16);
             four(B0, E0, min(4u, end - j));
             j = nx;
             if (j >= end || (alive & grp) == 0ull) break;
             nx = j + 4u + (__float_as_uint(B1[2]) >> 31);
-            if (nx < end) B0 = sload16(boxes + nx), E0 = sload8(ids + 2 * (size_t)nx);
+            if (nx < end) B0 = sload16(lists + 6 * (size_t)nx), E0 = sload8(lists + 6 * (size_t)nx + 16);
             four(B1, E1, min(4u, end - j));
             j = nx;
             if (j >= end) break;
@@ -4328,7 +4329,7 @@ static LightCells light_cells(const SceneView& sv, const LightProj& lp) {
 }
 
 hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n_tris_total,
-                       uint32_t* d_counts, float4* d_boxes, uint32_t* d_ids, uint32_t cap_shift, uint32_t max_mean,
+                       uint32_t* d_counts, float* d_lists, uint32_t cap_shift, uint32_t max_mean,
                        uint32_t* d_flags, uint32_t* d_redo, bool redo_all, hipStream_t s) {
     if (lp.key_bits < 2 || lp.key_bits > 24 || (lp.key_bits & 1u) || sv.n_objs > RT_LCELL_MAX_OBJS ||
         n_tris_total >= (1u << RT_LCELL_ID_BITS) || lp.key_bits + cap_shift > 31u)
@@ -4339,7 +4340,7 @@ hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const Ligh
     e = hipMemsetAsync(d_flags, 0, 32, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lcell_bin, dim3(grid_for(n_tris_total, 256)), dim3(256), 0, s, sv, p, lp, lc, n_tris_total, d_counts,
-                       d_boxes, d_ids, cap_shift);
+                       d_lists, cap_shift);
     hipLaunchKernelGGL(k_lcell_check, dim3(std::min(64u, grid_for(lc.n_cells, 256))), dim3(256), 0, s, d_counts, lc.n_cells,
                        1u << cap_shift, max_mean, d_flags, CellsTail{sv.leaf_gate, d_redo, redo_all ? 1u : 0u});
     return hipGetLastError();
@@ -4347,13 +4348,13 @@ hipError_t lcell_lists(const SceneView& sv, const DevRenderParams& p, const Ligh
 
 hipError_t shadow_cells(const SceneView& sv, const DevRenderParams& p, const LightProj& lp, uint32_t n,
                         const uint32_t* d_keys, const uint32_t* d_vals, const float4* d_samp, uint32_t* d_state,
-                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float4* d_boxes,
-                        const uint32_t* d_ids, uint32_t cap_shift, uint32_t* d_flags, uint32_t* d_redo, hipStream_t s) {
+                        DevStats* d_stats, const uint32_t* d_n_valid, const uint32_t* d_counts, const float* d_lists,
+                        uint32_t cap_shift, uint32_t* d_flags, uint32_t* d_redo, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = xcd_grid(grid_for(n, 64));
 #define RT_SC_LAUNCH(ST, ONE)                                                                                          \
     hipLaunchKernelGGL((k_shadow_cells<ST, ONE>), dim3(grid), dim3(64), 0, s, sv, p, lp, d_keys, d_vals, d_samp, d_state, \
-                       d_stats, d_n_valid, d_counts, d_boxes, d_ids, cap_shift, d_flags)
+                       d_stats, d_n_valid, d_counts, d_lists, cap_shift, d_flags)
     if (d_stats) {
         if (sv.n_objs == 1) RT_SC_LAUNCH(true, true);
         else RT_SC_LAUNCH(true, false);
