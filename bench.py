@@ -209,6 +209,76 @@ def pmc_traffic(kernel):
     return out
 
 
+def scatter_order_probe(scene, objects):
+    """Sorted against unsorted scatter rays: ten cosine-weighted rays off every camera-ray hit of a
+    960 x 540 x 4 frame of the diffuse-bounce scene, traced by the batch nearest-hit call (the same
+    persistent per-lane walk as k_wf_bounce) in the frame's own order, sorted by origin cell and direction
+    octant, and shuffled. The rates are the walk's alone: the sort that would feed it is not in them
+    (torch does it here; in a frame it would be a radix sort of the keys plus a gather of 24 bytes a ray)."""
+    import torch
+
+    dev, W, H = "cuda", 960, 540
+    sh = torch.cuda.current_stream().cuda_stream
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    blk = ((ys // 8) * ((W + 7) // 8) + xs // 8) * 64 + (ys % 8) * 8 + xs % 8     # pixels in 8 x 8 blocks, as a frame has them
+    order = torch.argsort(blk.reshape(-1))
+    px = xs.reshape(-1)[order].repeat_interleave(4).float()
+    py = ys.reshape(-1)[order].repeat_interleave(4).float()
+    smp = torch.arange(4, device=dev).repeat(W * H)
+    ox = torch.where(smp % 2 == 1, 0.75, 0.25)
+    oy = torch.where((smp == 1) | (smp == 2), 0.75, 0.25)
+    d = torch.stack([(2 * (px + ox) / W - 1) * float(W // H), 1 - 2 * (py + oy) / H, torch.ones_like(px)], 1)
+    rays = torch.cat([torch.zeros_like(d), d], 1).contiguous()
+    n0 = rays.shape[0]
+    out = torch.zeros(n0 * 4, dtype=torch.int32, device=dev)
+    scene.trace_closest_device(rays.data_ptr(), n0, out.data_ptr(), sh)
+    torch.cuda.synchronize()
+    o4 = out.view(n0, 4)
+    hit = o4[:, 0] != -1
+    t = o4[:, 1].view(torch.float32)
+    normals = torch.from_numpy(np.ascontiguousarray(objects[0]["tri_data"][:, :3])).to(dev)
+    nrm = normals[o4[hit, 0].long()]            # a soup's hit ids are its input order
+    pos = d[hit] * t[hit, None] + nrm * 1e-5
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    nn, pp = nrm.repeat_interleave(10, 0), pos.repeat_interleave(10, 0)
+    u1 = torch.rand(nn.shape[0], device=dev, generator=g)
+    u2 = torch.rand(nn.shape[0], device=dev, generator=g)
+    st_, ct, psi = torch.sqrt(u1), torch.sqrt(1 - u1), 2 * np.pi * u2
+    arb = torch.where(nn[:, 2:3].abs() < 1e-6, torch.tensor([0.0, 0.0, 1.0], device=dev), torch.tensor([1.0, 0.0, 0.0], device=dev))
+    t1 = torch.nn.functional.normalize(torch.cross(nn, arb, dim=1), dim=1)
+    t2 = torch.nn.functional.normalize(torch.cross(nn, t1, dim=1), dim=1)
+    dd = torch.nn.functional.normalize((st_ * torch.cos(psi))[:, None] * t1 + (st_ * torch.sin(psi))[:, None] * t2 + ct[:, None] * nn, dim=1)
+    n = dd.shape[0]
+
+    def spread3(v):
+        v = v & 0x3FF
+        v = (v | (v << 16)) & 0x30000FF
+        v = (v | (v << 8)) & 0x300F00F
+        v = (v | (v << 4)) & 0x30C30C3
+        return (v | (v << 2)) & 0x9249249
+
+    q = torch.clamp(((pp - torch.tensor([-10.0, -10.0, 5.0], device=dev)) / 20.0 * 1024).long(), 0, 1023)
+    morton = spread3(q[:, 0]) | (spread3(q[:, 1]) << 1) | (spread3(q[:, 2]) << 2)
+    octant = (dd[:, 0] > 0).long() | ((dd[:, 1] > 0).long() << 1) | ((dd[:, 2] > 0).long() << 2)
+    orders = {"frame_order": torch.arange(n, device=dev),
+              "sorted_by_origin_cell_and_octant": torch.argsort(((morton >> 15) << 3) | octant, stable=True),
+              "shuffled": torch.randperm(n, device=dev, generator=g)}
+    res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    rates = {}
+    for name, idx in orders.items():
+        r = torch.cat([pp[idx], dd[idx]], 1).contiguous()
+        scene.trace_closest_device(r.data_ptr(), n, res.data_ptr(), sh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            scene.trace_closest_device(r.data_ptr(), n, res.data_ptr(), sh)
+        torch.cuda.synchronize()
+        rates[name] = n / ((time.perf_counter() - t0) / 3) / 1e6
+    return {"scatter_rays": n, "unit": "Mrays/s (batch nearest-hit call, the walk alone)", **rates,
+            "note": "k_wf_bounce traces its rays in frame order: the gain of sorted rays is smaller than a sort of the rays would cost"}
+
+
 def bounce_roofline(ctx, args, new_event, elapsed_ms, scene):
     """A short run of the diffuse-bounce workload (config 4: soup-10M, 3840x2160, four samples, ten
     scatter rays off every hit and the shadow rays of all of them): frame time, and the roofline
@@ -643,10 +713,12 @@ def main():
             scene.close()
             out["teapot"] = teapot_leg(ctx, args, not args.no_cpu_baseline)
             t0 = time.perf_counter()
-            scene10 = Scene(ctx, scenes.soup(args.bounce_tris, 0x5EED0002))
+            objects10 = scenes.soup(args.bounce_tris, 0x5EED0002)
+            scene10 = Scene(ctx, objects10)
             build10_s = time.perf_counter() - t0
             out["roofline_bounce"] = bounce_roofline(ctx, args, new_event, elapsed_ms, scene10)
             out["roofline_bounce"]["scene_generate_and_build_s"] = build10_s
+            out["roofline_bounce"]["sorted_vs_unsorted"] = scatter_order_probe(scene10, objects10)
             out["config5"] = config5_leg(ctx, args, 0, 1, None, dist, red_dev, scene10)
             scene10.close()
         if config5 is not None:
