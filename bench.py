@@ -6,7 +6,7 @@ Workload (the configuration the headline metric is quoted on): the synthetic
 camera rays generated on the device, nearest-hit search, one sun shadow ray per lit hit, shading,
 sub-sample average, RGBA8. One step = one frame. Mrays/s counts nearest-hit plus shadow searches.
 In this configuration the library finds the camera rays' nearest hits by projecting the triangles
-onto the sample grid (same results as the tree walk, see DESIGN.md); `value` is that default path and
+onto the sample grid (same results as the tree walk); `value` is that default path and
 `value_tree_walk` the same frame with every ray walked through the tree (RAYS_HIP_RASTER=0).
 A short run of the diffuse-bounce workload (soup-10M, config 4) adds a roofline entry for the
 kernel that traces the incoherent secondary rays.

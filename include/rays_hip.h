@@ -121,7 +121,7 @@ typedef struct {
  * runs on the host only. */
 int  rt_ctx_create(const int* devices, int n, rt_ctx** out);
 void rt_ctx_destroy(rt_ctx*);
-/* The library's switches (environment variables RAYS_HIP_*, listed in INTEGRATION.md: which search
+/* The library's switches (environment variables RAYS_HIP_*: which search
  * a frame's rays take, limits, verbosity) are read when the context is created; this reads them
  * again, for hosts that change them between calls (the tests and the benchmark do). No reference
  * counterpart: the reference's switches are compile-time constants (src/main.rs:29-36). */
