@@ -13,7 +13,7 @@ ctx = Context(0); sc = Scene(ctx, objs); t2 = time.perf_counter()
 print(f"soup {n}: generate {t1-t0:.1f} s, build {t2-t1:.1f} s", flush=True)
 frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
 for dd, label in ((1, "primary+shadow"), (2, "diffuse x10")):
-    p = render_params(W, H, 2, reflect_depth=4, diffuse_depth=dd, sun=scenes.SUN_T0)
+    p = render_params(W, H, 2, reflect_depth=4, diffuse_depth=dd, sun=scenes.SUN_T0, seed=int(os.environ.get("PROBE_SEED", "0")))
     st = sc.render_device_stats(p, frame.data_ptr())
     sc.render_device(p, frame.data_ptr()); torch.cuda.synchronize()
     t = time.perf_counter()
