@@ -1331,8 +1331,8 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             // (A leaf lane's fourth load reads into the next record; the array is padded for it. Asked for by
             // all lanes and pinned here, the four loads go out back to back before either kind computes.)
             float4 q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];
-            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                              "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+            asm volatile("" :: "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                              "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w), "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
             bool need_pop = true;
             if (!at_leaf) {
                 uint32_t next;
@@ -2132,12 +2132,6 @@ __global__ void k_camera_table(SceneView sv, DevRenderParams p, float* __restric
 #define RT_RASTER_SLOP 0.125f   // samples: rounding of the projected vertices (hardware reciprocal, float products)
 #endif
 #define RT_RASTER_QUEUE 128     // candidate samples a wave holds before it tests 64 of them
-#ifndef RT_GATE_RASTER
-#define RT_GATE_RASTER 1
-#endif
-#ifndef RT_GATE_CELLS
-#define RT_GATE_CELLS 1
-#endif
 #ifdef RT_DEBUG_RASTER
 // Debug build only: triangle id, sample column, sample row to report on.
 __device__ uint32_t g_dbg[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
@@ -3137,7 +3131,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
             const rt_f3 inv = f3(lds.idx[sul[u]], lds.idy[swl[u]], 1.0f);
-            if (RT_GATE_RASTER && hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv)) {
+            if (hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv)) {
                 const unsigned long long key = rescan(sul[u], swl[u]);
                 hit_any[u] = key != RT_ZKEY_NONE;
                 hs[u].tri = hit_any[u] ? (uint32_t)key : 0u;
@@ -3652,7 +3646,7 @@ __global__ __launch_bounds__(64, 8) void k_shadow_cells(SceneView sv, DevRenderP
     // too early: it goes to the queue of k_shadow_redo, which runs the reference's own search for it.
     bool occ = act && !((alive >> lane) & 1ull);
     const uint32_t tri = lds.occluder[lane];
-    if (RT_GATE_CELLS && occ && tri != 0xFFFFFFFFu) {
+    if (occ && tri != 0xFFFFFFFFu) {
         const rt_f3 ro = f3(lds.ray[0][lane], lds.ray[1][lane], lds.ray[2][lane]);
         const rt_f3 rd = f3(lds.ray[3][lane], lds.ray[4][lane], lds.ray[5][lane]);
         const CellsTail* ct = reinterpret_cast<const CellsTail*>(flags + 16);
