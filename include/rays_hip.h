@@ -174,7 +174,7 @@ int  rt_trace_any_device(rt_scene*, const rt_ray* d_rays, uint64_t n, uint8_t* d
 /* rt_trace_closest_device for callers that cannot allocate: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc. No counterpart in the reference. Same arguments
  * and results as rt_trace_closest_device; it calls no hipMalloc / hipFree or any other allocating
- * routine. The work counter of its kernel lives in a 256-byte file-scope device array that every GPU
+ * routine. The work counter of its kernel lives in a 512-byte file-scope device array that every GPU
  * the library runs on holds until the process ends (rt_ctx_create looks its address up once per
  * device). At most 2^31 rays per call (RT_ERR_UNSUPPORTED beyond). Every call on a GPU uses that
  * GPU's array: calls that overlap on one GPU (different streams, or contexts on the same device)

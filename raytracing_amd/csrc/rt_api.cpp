@@ -184,11 +184,17 @@ void RtOptions::read_env() {
     sort_bits = (long)num("RAYS_HIP_SORT_BITS", 0.0);
 }
 
-// A zeroed work counter for one launch on `stream` (the caller holds ctx->mu).
+// Scenes below this many triangles use all the walk's counters (RAYS_HIP_WALK_SHARDS_BELOW; tuning).
+static uint32_t walk_shards_below() {
+    if (const char* e = std::getenv("RAYS_HIP_WALK_SHARDS_BELOW")) return (uint32_t)std::strtoul(e, nullptr, 10);
+    return 2000000u;
+}
+
+// A zeroed block of work counters for one launch on `stream` (the caller holds ctx->mu).
 int take_counter(rt_ctx* ctx, hipStream_t stream, uint32_t** out) {
-    if (!ctx->d_counters) HIP_TRY(hipMalloc((void**)&ctx->d_counters, rt_ctx::N_COUNTERS * 64));
-    uint32_t* c = ctx->d_counters + 16 * (ctx->next_counter++ % rt_ctx::N_COUNTERS);
-    HIP_TRY(hipMemsetAsync(c, 0, 4, stream));
+    if (!ctx->d_counters) HIP_TRY(hipMalloc((void**)&ctx->d_counters, (size_t)rt_ctx::N_COUNTERS * RT_COUNTER_BYTES));
+    uint32_t* c = ctx->d_counters + (RT_COUNTER_BYTES / 4u) * (ctx->next_counter++ % rt_ctx::N_COUNTERS);
+    HIP_TRY(hipMemsetAsync(c, 0, RT_COUNTER_BYTES, stream));
     *out = c;
     return RT_OK;
 }
@@ -1248,6 +1254,13 @@ int rt_scene_build_ex(rt_ctx* ctx, const rt_object_desc* objs, uint32_t n_objs, 
     s->view.leaf_bounds = d_leaf_bounds;
     s->view.leaf_gate = d_leaf_gate;
     // triangle id lies in leaf id / 8 as long as no object with trailing triangles comes before it
+    // How the persistent walks hand out the shared half of a launch's rays: through one counter where a
+    // ray is a long walk, through RT_COUNTER_SHARDS of them where rays are cheap and the one word's
+    // 88 requests a microsecond would bound the launch (the reference's scene with its own constants:
+    // 5.3 -> 4.3 ms a frame, a 100,000-triangle soup's bounce frame 46.7 -> 35.0 ms; soups of three and
+    // ten million triangles are 2 % slower that way, their waves then work on eight parts of the frame at
+    // a time and share less of the tree in the caches; at one million the two are level).
+    s->view.walk_counter_shards = s->n_tris_total < walk_shards_below() ? RT_COUNTER_SHARDS : 1u;
     s->view.leaves_uniform = 1u;
     s->view.n_rest_total = s->n_rest_total;
     for (size_t o = 0; o < s->objects.size(); ++o)

@@ -37,6 +37,12 @@ struct DevObject {
 static_assert(sizeof(DevObject) == 64, "DevObject layout");
 
 // Everything a search needs, passed to kernels by value.
+// The persistent walks hand out the shared part of a launch's rays through RT_COUNTER_SHARDS counters, one
+// per 64-byte line (a single word shared by all 8 XCDs serves about 88 requests a microsecond, which
+// bounds launches of cheap rays): a launch's counter block is RT_COUNTER_BYTES, zero before the launch.
+#define RT_COUNTER_SHARDS 8u
+#define RT_COUNTER_BYTES (RT_COUNTER_SHARDS * 64u)
+
 struct SceneView {
     const DevObject* objs;
     uint32_t n_objs;
@@ -54,6 +60,7 @@ struct SceneView {
     uint32_t n_rest_total;      // trailing triangles of all objects together
     const float* tri_data;      // reference order: normal xyz, color rgb per triangle
     const float* rest_verts;    // a xyz, b xyz, c xyz of every trailing triangle
+    uint32_t walk_counter_shards;  // counters the persistent walks hand their shared rays out through: 1 or RT_COUNTER_SHARDS
     float beam_limit;           // widest beam footprint worth a beam walk (scene extent / 128)
     float scene_extent;         // largest side of the bounding box of the objects that have a tree
 };

@@ -1202,6 +1202,11 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
     // Whole rounds of one chunk per wave inside the first RT_STATIC_PCT per cent of the rays.
     const uint32_t static_turns = (uint32_t)((uint64_t)n_rays * RT_STATIC_PCT / 100u) / (gridDim.x * (uint32_t)RT_CHUNK);
     uint32_t turn = 0;
+    const uint32_t shared_from = static_turns * gridDim.x * (uint32_t)RT_CHUNK;
+    const uint32_t shards = sv.walk_counter_shards;
+    // rays per stretch of the shared part: whole chunks
+    const uint32_t shard_rays = ((n_rays - shared_from + shards * (uint32_t)RT_CHUNK - 1u) / (shards * (uint32_t)RT_CHUNK)) * (uint32_t)RT_CHUNK;
+    uint32_t shard = blockIdx.x % shards, shards_left = shards;
     uint32_t j = 0, oi = 0, cur = 0, local_best = 0;
     rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = f3(0.0f, 0.0f, 1.0f), inv = d;
     float closest = RT_INF;
@@ -1221,11 +1226,24 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                     base = (turn * gridDim.x + blockIdx.x) * (uint32_t)RT_CHUNK;
                     ++turn;
                 } else {
+                    // The shared rays are cut into `shards` stretches (1 or RT_COUNTER_SHARDS, the scene's
+                    // choice: see SceneView), each with a counter in a cache line of its own; a wave starts
+                    // at the stretch of its number and moves on to the next one when a stretch is used up
+                    // (a stretch that is used up stays so).
                     const int first = __builtin_ctzll(idle);
-                    uint32_t got = 0;
-                    if ((int)lane == first) got = atomicAdd(counter, (uint32_t)RT_CHUNK);
-                    base = static_turns * gridDim.x * (uint32_t)RT_CHUNK +
-                           (uint32_t)__builtin_amdgcn_readlane((int)got, first);
+                    base = n_rays;
+                    while (shards_left != 0u) {
+                        uint32_t got = 0;
+                        if ((int)lane == first) got = atomicAdd(counter + 16u * shard, (uint32_t)RT_CHUNK);
+                        got = (uint32_t)__builtin_amdgcn_readlane((int)got, first);
+                        const uint32_t lo = shared_from + shard * shard_rays;
+                        if (got < shard_rays && lo + got < n_rays) {
+                            base = lo + got;
+                            break;
+                        }
+                        shard = shard + 1u == shards ? 0u : shard + 1u;
+                        --shards_left;
+                    }
                 }
                 exhausted = base >= n_rays;
                 chunk_next = exhausted ? 0u : base;

@@ -5,7 +5,7 @@
 // array instead and calls no allocating routine at all.
 //
 // The array exists once per GPU, at an address of its own on each, and keeps whatever the last call
-// left in it: the counter word is cleared on the caller's stream before every launch. Two calls
+// left in it: the counters are cleared on the caller's stream before every launch. Two calls
 // that overlap on one GPU (different streams, or host threads using different contexts on one
 // device) share the counter and race; calls on one stream, or ordered by the caller, do not.
 
@@ -16,9 +16,10 @@
 #include "rt_api_internal.h"
 #include "rt_kernels.h"
 
-// Device memory of the entry point beyond its inputs and outputs: the ray hand-out counter of
-// k_trace_closest_persistent (first word). RT_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.
-#define RT_NOALLOC_SCRATCH_BYTES 256
+// Device memory of the entry point beyond its inputs and outputs: the ray hand-out counters of
+// k_trace_closest_persistent (eight words, one per 64-byte line). RT_NOALLOC_SCRATCH_BYTES = 512 per GPU,
+// held until the process ends.
+#define RT_NOALLOC_SCRATCH_BYTES RT_COUNTER_BYTES
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 
 // Most rays one call takes: the persistent kernel's 32-bit ray index with the counter's overshoot
@@ -61,7 +62,7 @@ extern "C" int rt_trace_closest_device_noalloc(rt_scene* s, const rt_ray* d_rays
     HIP_TRY(hipSetDevice(ctx->device));
     uint32_t* counter = static_cast<uint32_t*>(ctx->noalloc_scratch);
     if (!counter) return rt_fail(RT_ERR_DEVICE, "scratch array was not set up for device %d", ctx->device);
-    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(counter, 0, RT_NOALLOC_SCRATCH_BYTES, (hipStream_t)stream));
     HIP_TRY(rtk::trace_closest(s->view, d_rays, n, d_out, counter, ctx->opt.trace, (hipStream_t)stream));
     return RT_OK;
 }
