@@ -1203,7 +1203,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
     const uint32_t static_turns = (uint32_t)((uint64_t)n_rays * RT_STATIC_PCT / 100u) / (gridDim.x * (uint32_t)RT_CHUNK);
     uint32_t turn = 0;
     const uint32_t shared_from = static_turns * gridDim.x * (uint32_t)RT_CHUNK;
-    const uint32_t shards = sv.walk_counter_shards;
+    const uint32_t shards = sv.walk_counter_shards == RT_COUNTER_SHARDS ? RT_COUNTER_SHARDS : 1u;   // (never zero)
     // rays per stretch of the shared part: whole chunks
     const uint32_t shard_rays = ((n_rays - shared_from + shards * (uint32_t)RT_CHUNK - 1u) / (shards * (uint32_t)RT_CHUNK)) * (uint32_t)RT_CHUNK;
     uint32_t shard = blockIdx.x % shards, shards_left = shards;
