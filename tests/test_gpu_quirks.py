@@ -246,3 +246,32 @@ def test_default_scene_by_projection(ctx, oracle, default_objects, monkeypatch):
     10,000 units wide that pass behind the camera; the teapots are projected, the floor is tested per
     sample."""
     _projected_frame_check(ctx, oracle, default_objects, monkeypatch, [(320, 180, 2), (200, 200, 1), (160, 90, 4)])
+
+
+@pytest.mark.parametrize("shards_below", ["0", "4000000000"])
+def test_batch_sizes_around_the_hand_out_boundaries(ctx, soup64k, monkeypatch, shards_below):
+    """The persistent walk gives the first half of a batch to its waves by number and hands the rest out in
+    chunks of 64 through one counter or through eight (small scenes; RAYS_HIP_WALK_SHARDS_BELOW picks at scene
+    build). Batches of one ray, of a chunk more or less, of a whole grid's worth (8,192 waves x 64) more or
+    less and of no multiple of anything must come out ray for ray as from the plain per-lane walk."""
+    monkeypatch.setenv("RAYS_HIP_WALK_SHARDS_BELOW", shards_below)
+    g = Scene(ctx, soup64k)
+    try:
+        rng = np.random.default_rng(11)
+        n_max = 2 * 8192 * 64 + 777
+        org = rng.uniform(-8, 8, (n_max, 3)).astype(np.float32) + np.array([0, 0, 12], dtype=np.float32)
+        d = rng.normal(size=(n_max, 3)).astype(np.float32)
+        rays = np.concatenate([org, d], axis=1)
+        monkeypatch.setenv("RAYS_HIP_TRACE", "lane")
+        want = g.trace_closest(rays)
+        want_any = g.trace_any(rays)
+        monkeypatch.delenv("RAYS_HIP_TRACE")
+        for n in (1, 63, 64, 65, 8 * 64 + 1, 8192 * 64 - 1, 8192 * 64, 8192 * 64 + 65, n_max):
+            got = g.trace_closest(rays[:n])
+            assert np.array_equal(got["tri"], want["tri"][:n]), n
+            hit = got["tri"] != 0xFFFFFFFF
+            assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][:n][hit].view(np.uint32)), n
+            assert np.array_equal(g.trace_any(rays[:n]), want_any[:n]), n
+        assert (want["tri"] != 0xFFFFFFFF).sum() > 1000
+    finally:
+        g.close()
