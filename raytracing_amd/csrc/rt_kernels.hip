@@ -48,9 +48,9 @@ __device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2
 // before its own box) while an earlier triangle lies in between is the one case left out.
 // `ob` is the triangle's object, `id` its global number (not a trailing triangle).
 // lo4, hi4: the leaf's entry of SceneView::leaf_gate (its box, and which of the two tests it takes).
-__device__ __forceinline__ bool ref_leaf_gate(float4 lo4, float4 hi4, rt_f3 o, rt_f3 inv) {
+__device__ __forceinline__ bool ref_leaf_gate(float4 lo4, float4 hi4, rt_f3 o, rt_f3 inv, float ray_length = RT_INF) {
     const rt_f3 lo = f3(lo4.x, lo4.y, lo4.z), hi = f3(hi4.x, hi4.y, hi4.z);
-    return lo4.w != 0.0f ? packed_box_hit(lo, hi, o, inv, RT_INF) : box_intersection_check(o, inv, lo, hi);
+    return lo4.w != 0.0f ? packed_box_hit(lo, hi, o, inv, ray_length) : box_intersection_check(o, inv, lo, hi);
 }
 __device__ __forceinline__ bool ref_leaf_gate(const SceneView& sv, const DevObject& ob, uint32_t id, rt_f3 o, rt_f3 inv) {
     const float4* lg = sv.leaf_gate + 2 * (size_t)(ob.leaf_base + ((id - ob.tri_base) >> 3));
@@ -3089,23 +3089,50 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     // (the normal's address comes out of the nearest-hit word: two dependent reads per sample).
     constexpr uint32_t U = RT_RECORD_ROUND;
     static_assert(RT_RTILE * RT_RTILE % (64u * RT_RTILE_GROUP * U) == 0, "the tile's samples are dealt out in rounds of U per lane");
-    // A sample's nearest hit over again, with every accepted triangle put through the reference's leaf
-    // gate (ref_leaf_gate): for the rare sample whose nearest hit does not pass it. The tile's list holds
-    // every triangle the exact test can accept at any of the tile's samples.
+    // A sample's nearest hit over again, the way the reference finds it (src/main.rs:93-153): the triangles
+    // that the exact test accepts are gone through in the order of their ids, the nearest so far in
+    // `closest`; a leaf's triangles count only if its box passes the test with the ray cut at the `closest`
+    // of the moment its packet of eight leaves began (the last n_leaves % 8 leaves of an object: the
+    // object-box form of the test, which knows no length), and a triangle replaces the nearest only if
+    // strictly nearer. For the rare sample whose nearest hit does not pass its leaf's box with the ray cut at
+    // the hit itself: then, and only then, the outcome can depend on that order (when the box does pass,
+    // it passes for every earlier `closest` too, all of which are at least as large, and the nearest hit
+    // is the reference's). The tile's list holds every triangle the exact test can accept at any of the
+    // tile's samples, in no particular order, so the next id is looked for anew each time: a few thousand
+    // triangle tests for one sample in many millions.
     auto rescan = [&](uint32_t sl, uint32_t wl) -> unsigned long long {
-        const rt_f3 d = f3(lds.dx[sl], lds.dy[wl], 1.0f), inv = g_recip(d);
+        const rt_f3 d = f3(lds.dx[sl], lds.dy[wl], 1.0f), inv = f3(lds.idx[sl], lds.idy[wl], 1.0f);
         unsigned long long best = RT_ZKEY_NONE;
-        for (uint32_t i = 0; i < n_list; ++i) {
-            const uint32_t id = list[first + i];
-            const float4* r = recs + (size_t)RT_RREC * id;
-            const float4 r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
-            const uint32_t ow = __float_as_uint(r2.w);
-            const rt_tri_eval ev = tri_intersect(f3(r3.x, r3.y, r3.z), f3(r3.w, r4.x, r4.y), f3(r4.z, r4.w, r5.x), o, d);
-            if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
-            if (!(ow & 0x80000000u) && !raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + sl, (uint32_t)sw0 + wl)) continue;
-            if (!ref_leaf_gate(sv, sv.objs[ow & 0x7FFFFFFFu], id, o, inv)) continue;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(ev.t) << 32) | id;
-            best = key < best ? key : best;
+        float closest = RT_INF, packet_closest = RT_INF;
+        uint32_t last = 0, packet = 0xFFFFFFFFu, packet_obj = 0xFFFFFFFFu;
+        bool any_before = false;
+        for (;;) {
+            uint32_t nid = 0xFFFFFFFFu, now = 0;
+            float nt = 0.0f;
+            for (uint32_t i = 0; i < n_list; ++i) {
+                const uint32_t id = list[first + i];
+                if ((any_before && id <= last) || id >= nid) continue;
+                const float4* r = recs + (size_t)RT_RREC * id;
+                const float4 r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+                const uint32_t ow = __float_as_uint(r2.w);
+                const rt_tri_eval ev = tri_intersect(f3(r3.x, r3.y, r3.z), f3(r3.w, r4.x, r4.y), f3(r4.z, r4.w, r5.x), o, d);
+                if (ev.failed || !(ev.t > 0.0f) || !(ev.t < RT_INF)) continue;
+                if (!(ow & 0x80000000u) && !raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + sl, (uint32_t)sw0 + wl)) continue;
+                nid = id, nt = ev.t, now = ow & 0x7FFFFFFFu;
+            }
+            if (nid == 0xFFFFFFFFu) break;
+            any_before = true, last = nid;
+            const DevObject& ob = sv.objs[now];
+            const uint32_t leaf = ob.leaf_base + ((nid - ob.tri_base) >> 3);
+            // a packet is eight consecutive leaves of one object, counted from the object's first
+            const uint32_t pk = (nid - ob.tri_base) >> 6;
+            if (pk != packet || now != packet_obj) packet = pk, packet_obj = now, packet_closest = closest;
+            const float4* lg = sv.leaf_gate + 2 * (size_t)leaf;
+            if (!ref_leaf_gate(lg[0], lg[1], o, inv, packet_closest)) continue;
+            if (closest > nt) {
+                closest = nt;
+                best = ((unsigned long long)__float_as_uint(nt) << 32) | nid;
+            }
         }
         return best;
     };
@@ -3143,13 +3170,14 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
             leaf_lo[u] = lg[0], leaf_hi[u] = lg[1];
         }
         // The reference tests a triangle only for rays that pass the box of its leaf (ref_leaf_gate): the
-        // nearest hit is checked against it, and the few samples whose nearest hit fails are worked out again.
+        // nearest hit is checked against it, with the ray cut at the hit, and the few samples whose nearest
+        // hit fails are worked out again in the reference's order.
         // (A projected scene's eight-wide triangles fill whole leaves from triangle 0 on: objects with
         // trailing triangles come last, see rt_scene_build.)
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
             const rt_f3 inv = f3(lds.idx[sul[u]], lds.idy[swl[u]], 1.0f);
-            if (hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv)) {
+            if (hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv, hs[u].t)) {
                 const unsigned long long key = rescan(sul[u], swl[u]);
                 hit_any[u] = key != RT_ZKEY_NONE;
                 hs[u].tri = hit_any[u] ? (uint32_t)key : 0u;

@@ -98,6 +98,44 @@ def test_ray_in_the_plane_of_a_large_triangle(ctx, oracle, monkeypatch):
         o.close()
 
 
+def test_nearest_hit_whose_leaf_box_ends_an_ulp_behind_it(ctx, oracle, monkeypatch):
+    """Seed 60253 at 1920 x 1080: triangle 63289 (30 x 20 units, 0.39 deep) is the nearest triangle the
+    exact test accepts for sample 3 of pixel (1626, 82), an ulp nearer than triangle 60275 at t = 3.6285462.
+    The reference reaches 60275 first and then tests the box of 63289's leaf with the ray cut at that
+    distance: rounded as the box test rounds, the box begins an ulp behind it, and the leaf is never
+    looked into. The outcome depends on the order of the search, which projection has to play back for
+    such a sample (a nearest hit that fails its leaf's box with the ray cut at the hit itself)."""
+    from raytracing_amd import scenes
+    fuzz = _fuzz(monkeypatch)
+    objs, sun = _scene(fuzz, 60253)
+    w, h = 1920, 1080
+    p = render_params(w, h, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+    monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
+    monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+    g = Scene(ctx, objs)
+    o = oracle.OracleScene(objs)
+    try:
+        assert _stats(g, p)["camera_by_projection"] == 1
+        _, ids = g.render(p, want_hit_ids=True)
+        monkeypatch.setenv("RAYS_HIP_RASTER", "0")
+        _, ids_walk = g.render(p, want_hit_ids=True)
+        pix, sub = 82 * w + 1626, 3
+        ray = scenes.camera_rays(w, h, 2, pixels=[pix])[sub:sub + 1]
+        ref = o.trace_closest(ray)
+        assert ref["tri"][0] == 60275
+        assert ids_walk[4 * pix + sub] == 60275 and ids[4 * pix + sub] == 60275
+        # where the two paths still differ the projection has the oracle's triangle (four rays in the plane
+        # of an axis-aligned triangle 15 units wide, whose flat box the tree walk's rounding misses)
+        off = np.nonzero(ids != ids_walk)[0]
+        assert len(off) <= 8
+        for s in off:
+            ray = scenes.camera_rays(w, h, 2, pixels=[int(s) // 4])[int(s) % 4:int(s) % 4 + 1]
+            assert o.trace_closest(ray)["tri"][0] == ids[s]
+    finally:
+        g.close()
+        o.close()
+
+
 @pytest.mark.parametrize("seed", [20094, 5003])
 def test_rays_sent_back_to_the_reference_search(ctx, monkeypatch, seed):
     """A ray whose occluder fails the leaf's box test goes to a second kernel that runs the reference's

@@ -19,7 +19,7 @@ seed = int(sys.argv[1])
 rng = np.random.default_rng(seed)
 sun = fuzz.sun_of(rng)
 objs = fuzz.scene_of(rng, sun)
-W, H = 640, 360
+W, H = fuzz.W, fuzz.H
 ctx = Context(0)
 g = Scene(ctx, objs)
 o = oracle_ffi.OracleScene(objs)
