@@ -25,6 +25,10 @@ struct LaneStats {
     uint32_t bytes = 0;  // structure bytes requested: a scalar load counts once per wave, a vector load per lane
 };
 
+// A nearest-hit result that stands for "not decided here": the wave-wide and the persistent walks
+// hand the rare ray whose answer may depend on the order of the reference's search (closest_needs_resolve)
+// to a second kernel, which runs the per-lane search with closest_resolve for it.
+#define RT_REDO 0xFFFFFFFEu
 struct HitD {
     uint32_t tri;
     uint32_t obj;
@@ -288,9 +292,234 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The order of the reference's search, where it decides. The reference goes through an object's
+// leaves in order, eight at a time, and tests a packet's eight boxes with the ray cut at the nearest
+// distance found so far (src/main.rs:98-111,127); a triangle then replaces the nearest only if strictly
+// nearer. The walks here return the least (t, id) among the triangles the exact test accepts, W. That
+// is the reference's answer whenever the box of W's leaf passes with the ray cut at W's own distance:
+// every distance the reference can hold before it reaches W's packet belongs to an accepted triangle,
+// so it is at least t_W, the box test only gets easier with a longer ray, and of the triangles at the
+// least distance W has the lowest number. It need not be when that test fails: W lies in the very
+// plane of its leaf's box (an axis-aligned wall) and the box's entry distance, rounded as the box test
+// rounds, comes out a few units of the last place behind W's t, rounded as the triangle test rounds; if
+// an earlier-numbered triangle E has its t in between (a coplanar neighbour, an overlapping layer), the
+// reference holds t_E when it comes to W's packet, culls the packet and keeps E.
+// closest_needs_resolve is the test, run once per ray and object that found a hit; closest_resolve plays
+// the reference back for the (rare) rays that fail it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool closest_needs_resolve(const SceneView& sv, uint32_t oi, rt_f3 o, rt_f3 inv, const HitD& hit) {
+    const DevObject& ob = sv.objs[oi];
+    const float4* lg = sv.leaf_gate + 2 * (size_t)(ob.leaf_base + ((hit.tri - ob.tri_base) >> 3));
+    return !ref_leaf_gate(lg[0], lg[1], o, inv, hit.t);
+}
+
+// These run for one ray in many thousands and are called, not inlined: a called function's registers count
+// towards every kernel that calls it, and the values it keeps across its own calls sit in the high
+// registers the calling convention preserves, so the ray and its result travel as one block of private
+// memory and each function keeps little.
+struct ResolveRay {
+    rt_f3 o, d;
+    float closest;   // in: the nearest distance as the object's walk left it; out: as the reference leaves it
+    HitD hit;        // likewise
+};
+
+// The packed part of the reference's search of one object (src/main.rs:100-153), r.closest and r.hit as the
+// objects before it left them.
+__device__ __noinline__ void ref_object_packed(const SceneView& sv, uint32_t oi, ResolveRay& r) {
+    const DevObject& ob = sv.objs[oi];
+    const rt_f3 o = r.o, d = r.d, inv = g_recip(d);
+    float closest = r.closest;
+    const uint32_t n_leaves = ob.n_tris / 8;
+    for (uint32_t l0 = 0; l0 < n_leaves; l0 += 8u) {
+        const float ray_length = closest;   // closest_splat when the packet's boxes are tested
+        uint32_t mask = 0;
+        for (uint32_t b = 0; b < 8u && l0 + b < n_leaves; ++b) {
+            const float4* lg = sv.leaf_gate + 2 * (size_t)(ob.leaf_base + l0 + b);
+            if (ref_leaf_gate(lg[0], lg[1], o, inv, ray_length)) mask |= 1u << b;
+        }
+        for (uint32_t b = 0; b < 8u; ++b) {
+            if (!(mask & (1u << b))) continue;
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t id = ob.tri_base + (l0 + b) * 8u + j;
+                const float* p = sv.tri9 + 9 * (size_t)id;
+                const rt_tri_eval ev = tri_intersect(ld3(p), ld3(p + 3), ld3(p + 6), o, d);
+                if (!ev.failed && ev.t > 0.0f && closest > ev.t) {
+                    closest = ev.t;
+                    r.hit.tri = id, r.hit.obj = oi, r.hit.t = ev.t, r.hit.u = ev.u, r.hit.v = ev.v;
+                }
+            }
+        }
+    }
+    r.closest = closest;
+}
+
+// An object's trailing n % 8 triangles as the reference tests them (src/main.rs:157-169): `closest` stays.
+__device__ __noinline__ void ref_object_rest(const SceneView& sv, uint32_t oi, ResolveRay& r) {
+    const DevObject& ob = sv.objs[oi];
+    const rt_f3 o = r.o, d = r.d;
+    const float closest = r.closest;
+    for (uint32_t k = 0; k < ob.n_rest; ++k) {
+        const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + k);
+        float t, u, v;
+        if (triangle_ray_hits(ld3(pv), ld3(pv + 3), ld3(pv + 6), o, d, closest, &t, &u, &v) && closest > t)
+            r.hit.tri = ob.tri_base + ob.n_tris - ob.n_rest + k, r.hit.obj = oi, r.hit.t = t, r.hit.u = u, r.hit.v = v;
+    }
+}
+
+// The whole of the reference's search up to and including the packed part of object `upto`
+// (src/main.rs:93-171): the last resort of closest_resolve.
+__device__ __noinline__ void ref_search_upto(const SceneView& sv, uint32_t upto, ResolveRay& r) {
+    r.closest = RT_INF;
+    r.hit.tri = RT_MISS, r.hit.obj = 0, r.hit.t = r.hit.u = r.hit.v = 0.0f;
+    for (uint32_t oi = 0; oi <= upto; ++oi) {
+        const DevObject& ob = sv.objs[oi];
+        if (!box_intersection_check(r.o, g_recip(r.d), ld3(ob.bbmin), ld3(ob.bbmax))) continue;
+        ref_object_packed(sv, oi, r);
+        if (oi != upto) ref_object_rest(sv, oi, r);   // (the caller goes on with the last object's trailing triangles)
+    }
+}
+
+// Entry distance of PackedBoxes::intersect (src/simd_accel.rs:342-370): the tmin of packed_box_hit.
+__device__ __forceinline__ float packed_box_entry(rt_f3 bmin, rt_f3 bmax, rt_f3 o, rt_f3 inv) {
+    const rt_f3 a = (bmin - o) * inv, b = (bmax - o) * inv;
+    const bool kx = signum_is_one(inv.x), ky = signum_is_one(inv.y), kz = signum_is_one(inv.z);
+    return x86_max(x86_max(kx ? a.x : b.x, ky ? a.y : b.y), kz ? a.z : b.z);
+}
+
+#define RT_RESOLVE_MAX 8
+#define RT_RESOLVE_STACK 40    // up to three children left waiting per level of a tree; a deeper one goes to the last resort
+struct NearList {
+    uint32_t n;
+    uint32_t ids[RT_RESOLVE_MAX];
+    float ts[RT_RESOLVE_MAX];
+};
+// Every triangle of the tree under `root` that the exact test accepts with t <= far, in the order of their
+// numbers. False when there are more than RT_RESOLVE_MAX (or the tree is deeper than any the host builds).
+// The walk of bvh_search with the ray's length fixed, a child at a time.
+__device__ __noinline__ bool collect_near(const SceneView& sv, uint32_t root, const ResolveRay& r, float far, NearList& out) {
+    uint32_t stack[RT_RESOLVE_STACK];
+    uint32_t sp = 0, n = 0;
+    uint32_t cur = root;
+    const rt_f3 o = r.o, d = r.d, inv = g_recip(d);
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const float4 A = np[2 * k], B = np[2 * k + 1];   // (lo.x lo.y lo.z hi.x) (hi.y hi.z ref pad)
+                const uint32_t c = __float_as_uint(B.z);
+                if (c == EMPTY) continue;
+                const float ax = (A.x - o.x) * inv.x, bx = (A.w - o.x) * inv.x;
+                const float ay = (A.y - o.y) * inv.y, by = (B.x - o.y) * inv.y;
+                const float az = (A.z - o.z) * inv.z, bz = (B.y - o.z) * inv.z;
+                // (minima and maxima that skip a NaN, as node_step's do: a child is kept when in doubt)
+                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), far));
+                // the walks' boxes are padded for the roundings of fma(plane, inv, -o * inv); this form
+                // rounds differently by a few units of the last place, far inside that padding
+                if (tn <= tf * 1.00001f + 1e-30f) {
+                    if (sp == RT_RESOLVE_STACK) return false;
+                    stack[sp++] = c;
+                }
+            }
+        } else {
+            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = (cur & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4* rec = sv.recs + 3 * (size_t)(first + i);
+                const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                const rt_tri_eval ev = tri_intersect(f3(ra.w, rb.x, rb.y), f3(rb.z, rb.w, rc.x), f3(ra.x, ra.y, ra.z), o, d);
+                if (ev.failed || !(ev.t > 0.0f) || !(ev.t <= far)) continue;
+                if (n == RT_RESOLVE_MAX) return false;
+                const uint32_t id = __float_as_uint(rc.y);
+                uint32_t k = n++;
+                while (k > 0 && out.ids[k - 1] > id) out.ids[k] = out.ids[k - 1], out.ts[k] = out.ts[k - 1], --k;
+                out.ids[k] = id, out.ts[k] = ev.t;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    out.n = n;
+    return true;
+}
+
+// Object oi's search has ended at hit W = (r.hit.tri, r.hit.t) with r.closest = r.hit.t, `before` was the
+// nearest distance when it began, and closest_needs_resolve said that the order may matter. Leaves r.hit and
+// r.closest as the reference's search of the object's packed triangles leaves them.
+// Which triangles can matter: the reference's answer F is an accepted triangle, so t_F >= t_W, and if
+// t_F > t_W the reference has culled W's packet with a distance below the entry distance of W's leaf, so
+// t_F < entry. The accepted triangles with t up to `far` = max(entry, t_W) are collected by a second walk
+// with the ray cut there (a handful), in the order of their numbers, and gone through as the reference
+// goes through them. Triangles farther than `far` take part in the reference's search only through the
+// nearest distance they leave behind, some value above `far`: a collected triangle's box test gives the
+// same answer for every such value unless its own entry distance lies above `far`, and then, or when
+// there are too many to collect, or when none of the collected ones is accepted, the reference's search
+// is run as it stands (ref_search_upto).
+// (in three called parts, so that none of them holds much across a call)
+__device__ __forceinline__ const float4* resolve_gate_of(const SceneView& sv, const DevObject& ob, uint32_t id) {
+    return sv.leaf_gate + 2 * (size_t)(ob.leaf_base + ((id - ob.tri_base) >> 3));
+}
+// `far` for the hit in r; NaN when the reference never looks into W's leaf (its answer may then lie anywhere behind W).
+__device__ __noinline__ float resolve_far(const SceneView& sv, uint32_t oi, const ResolveRay& r) {
+    const DevObject& ob = sv.objs[oi];
+    const rt_f3 o = r.o, inv = g_recip(r.d);
+    const float4* lg = resolve_gate_of(sv, ob, r.hit.tri);
+    const float4 lo4 = lg[0], hi4 = lg[1];
+    if (!ref_leaf_gate(lo4, hi4, o, inv)) return __uint_as_float(0x7FC00000u);
+    const float entry = packed_box_entry(f3(lo4.x, lo4.y, lo4.z), f3(hi4.x, hi4.y, hi4.z), o, inv);
+    return entry > r.hit.t ? entry : r.hit.t;   // (an entry that is NaN: t_W)
+}
+// The collected triangles gone through in the reference's order. False: the reference's search as it stands is needed.
+__device__ __noinline__ bool resolve_replay(const SceneView& sv, uint32_t oi, float before, float far, const NearList& near,
+                                            ResolveRay& r) {
+    const DevObject& ob = sv.objs[oi];
+    const rt_f3 o = r.o, inv = g_recip(r.d);
+    uint32_t best = RT_MISS;
+    float c = before;
+    uint32_t packet = 0xFFFFFFFFu;
+    float packet_closest = before;
+    for (uint32_t k = 0; k < near.n; ++k) {
+        const uint32_t pk = (near.ids[k] - ob.tri_base) >> 6;
+        if (pk != packet) packet = pk, packet_closest = c;
+        const float4* lg = resolve_gate_of(sv, ob, near.ids[k]);
+        const float4 lo4 = lg[0], hi4 = lg[1];
+        const bool open = ref_leaf_gate(lo4, hi4, o, inv), open_far = ref_leaf_gate(lo4, hi4, o, inv, far);
+        if (open != open_far) return false;   // depends on distances beyond `far`
+        const bool pass = packet_closest > far ? open_far : ref_leaf_gate(lo4, hi4, o, inv, packet_closest);
+        if (pass && c > near.ts[k]) c = near.ts[k], best = near.ids[k];
+    }
+    if (best == RT_MISS) return false;
+    if (best != r.hit.tri) {
+        const float* p = sv.tri9 + 9 * (size_t)best;
+        const rt_tri_eval ev = tri_intersect(ld3(p), ld3(p + 3), ld3(p + 6), r.o, r.d);
+        r.hit.tri = best, r.hit.obj = oi, r.hit.t = ev.t, r.hit.u = ev.u, r.hit.v = ev.v;
+        r.closest = ev.t;
+    }
+    return true;
+}
+__device__ __noinline__ void closest_resolve(const SceneView& sv, uint32_t oi, float before, ResolveRay& r) {
+    const float far = resolve_far(sv, oi, r);
+    bool done = false;
+    if (far == far) {
+        NearList near;
+        near.n = 0;
+        done = collect_near(sv, sv.objs[oi].root, r, far, near) && resolve_replay(sv, oi, before, far, near, r);
+    }
+    if (!done) ref_search_upto(sv, oi, r);
+}
+// The call, from a walk that has just ended object oi's tree with a nearer hit than `before`.
+__device__ __forceinline__ void closest_confirm(const SceneView& sv, uint32_t oi, rt_f3 o, rt_f3 d, rt_f3 inv, float before,
+                                                HitD& hit, float& closest) {
+    if (!closest_needs_resolve(sv, oi, o, inv, hit)) return;
+    ResolveRay r;
+    r.o = o, r.d = d, r.closest = closest, r.hit = hit;
+    closest_resolve(sv, oi, before, r);
+    hit = r.hit, closest = r.closest;
+}
+
 // trace_ray's nearest-hit search over the whole World, src/main.rs:93-171.
-template <bool STATS>
-__device__ __forceinline__ HitD closest_all(const SceneView& sv, rt_f3 o, rt_f3 d, LaneStack& stk,
+template <bool STATS, class Stack = LaneStack>
+__device__ __forceinline__ HitD closest_all(const SceneView& sv, rt_f3 o, rt_f3 d, Stack& stk,
                                             LaneStats& st) {
     const rt_f3 inv = g_recip(d);
     HitD h;
@@ -303,7 +532,11 @@ __device__ __forceinline__ HitD closest_all(const SceneView& sv, rt_f3 o, rt_f3 
         const DevObject& ob = sv.objs[oi];
         if (STATS) st.box += 1;
         if (!box_intersection_check(o, inv, ld3(ob.bbmin), ld3(ob.bbmax))) continue;
-        if (ob.root != EMPTY) bvh_search<false, STATS>(sv, ob.root, oi, o, d, inv, closest, h, stk, st);
+        if (ob.root != EMPTY) {
+            const float before = closest;
+            bvh_search<false, STATS>(sv, ob.root, oi, o, d, inv, closest, h, stk, st);
+            if (closest < before) closest_confirm(sv, oi, o, d, inv, before, h, closest);
+        }
         // Trailing n % 8 triangles, src/main.rs:157-169: scalar arithmetic, and `closest` is NOT
         // lowered by a hit here, so the last qualifying one wins and later objects still compare
         // against the old distance.
@@ -929,9 +1162,12 @@ __device__ __forceinline__ bool beam_try(const SceneView& sv, uint32_t root_ref,
 
 // The wave-coherent forms of closest_all / any_all. Every lane of the wave must call them
 // together; `active` says whether the lane carries a ray.
-template <bool STATS>
+// DEFER: a lane whose ray needs closest_resolve comes back with tri = RT_REDO instead of calling it (a
+// call inside a kernel that is held to 64 registers costs the kernel its register allocation).
+template <bool STATS, bool DEFER = false>
 __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o, rt_f3 d, bool active, uint2* beam_lds,
                                                    LaneStats& st) {
+    bool redo = false;
     const rt_f3 inv = g_recip(d);
     HitD h;
     h.tri = RT_MISS;
@@ -951,8 +1187,13 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
         const bool in_obj = active && box_intersection_check(o, inv, bbmin, bbmax);
         if (RT_BALLOT(in_obj) == 0ull) continue;
         if (root != EMPTY) {
+            const float before = closest;
             if (!beam_try<false, STATS>(sv, wide_root, oi, o, d, in_obj, closest, h, unused, beam_lds, st))
                 packet_search<false, STATS>(sv, root, oi, o, d, inv, in_obj, closest, h, unused, st);
+            if (closest < before) {
+                if (DEFER) redo = redo || closest_needs_resolve(sv, oi, o, inv, h);
+                else closest_confirm(sv, oi, o, d, inv, before, h, closest);
+            }
         }
         for (uint32_t r = 0; r < n_rest; ++r) {
             const char* pv = reinterpret_cast<const char*>(sv.rest_verts) + 36 * (size_t)(rest_base + r);
@@ -973,6 +1214,7 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
         }
     }
     h.closest = closest;
+    if (DEFER && redo) h.tri = RT_REDO;
     return h;
 }
 
@@ -1285,7 +1527,13 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
             // next object whose box the ray meets.
             if (in_obj) {
                 const DevObject& ob = sv.objs[oi];
-                for (uint32_t r = 0; r < ob.n_rest; ++r) {
+                // The object's tree is done. A hit of this object's (its trailing triangles come below, so
+                // hit.obj == oi says so) whose answer may depend on the reference's order ends the ray here
+                // with RT_REDO for a result: the kernel that follows the walk decides it.
+                bool redo = false;
+                if (!ANY && hit.tri != RT_MISS && hit.obj == oi) redo = closest_needs_resolve(sv, oi, o, inv, hit);
+                if (redo) hit.tri = RT_REDO, oi = sv.n_objs;
+                for (uint32_t r = 0; !redo && r < ob.n_rest; ++r) {
                     const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
                     float t, u, v;
                     if (STATS) st.tri += 1;
@@ -1400,13 +1648,48 @@ struct BatchSource {
     }
     __device__ __forceinline__ void emit(uint32_t j, const HitD& h, rt_f3, rt_f3) const {
         rt_hit r;
-        r.tri = h.tri;
+        r.tri = h.tri;   // (RT_REDO as it is: redo_marked finds it there)
         r.t = h.t;
         r.u = h.u;
         r.v = h.v;
         out[j] = r;
     }
+    __device__ __forceinline__ bool marked(uint32_t j) const { return out[j].tri == RT_REDO; }
+    __device__ __forceinline__ void flush(uint32_t, bool) const {}
 };
+
+// The rays a walk has left undecided (RT_REDO): the per-lane search with closest_resolve for each, through
+// the same source. Whole waves call this; n is wave-uniform.
+template <class Source>
+__device__ __forceinline__ void redo_marked(const SceneView& sv, uint32_t n, const Source& src) {
+    using Stack = LaneStackT<RT_STACK_LDS, 64>;
+    __shared__ uint2 s_stack[RT_STACK_LDS * 64];
+    uint2 stack_rest[Stack::REST];
+    Stack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    stk.spill = stack_rest;
+    LaneStats st;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+        const uint32_t idx = base + lane;
+        const bool m = idx < n && src.marked(idx);
+        if (__ballot(m) == 0ull) continue;
+        if (m) {
+            rt_f3 o, d;
+            if (src.init(idx, o, d)) {
+                const HitD h = closest_all<false>(sv, o, d, stk, st);
+                src.emit(idx, h, o, d);
+            }
+        }
+        if constexpr (Source::QUEUES) src.flush(lane, false);
+    }
+    if constexpr (Source::QUEUES) src.flush(lane, true);
+}
+__global__ __launch_bounds__(64) void k_trace_closest_redo(SceneView sv, const rt_ray* __restrict__ rays, uint32_t n,
+                                                           rt_hit* __restrict__ out) {
+    const BatchSource src{rays, out};
+    redo_marked(sv, n, src);
+}
 
 struct BatchAnySource {
     static constexpr bool QUEUES = false;
@@ -1453,7 +1736,7 @@ __global__ __launch_bounds__(64, 8) void k_trace_closest_wave(SceneView sv, cons
     rt_ray r;
     if (act) r = rays[i];
     else r = rt_ray{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}};
-    const HitD h = closest_all_packet<false>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), act, s_beam, st);
+    const HitD h = closest_all_packet<false, true>(sv, f3(r.o[0], r.o[1], r.o[2]), f3(r.d[0], r.d[1], r.d[2]), act, s_beam, st);
     if (act) {
         rt_hit o;
         o.tri = h.tri;
@@ -1948,6 +2231,7 @@ __global__ __launch_bounds__(BLOCK) void k_render(SceneView sv, DevRenderParams 
 #define RT_ST_HIT 1u
 #define RT_ST_LIT 2u
 #define RT_ST_OCC 4u
+#define RT_ST_REDO 8u   // the whole word: the sample's nearest hit is left to the kernel that follows (RT_REDO)
 
 // Workgroups are handed to the eight XCDs in turn, and each XCD has its own L2. The groups are
 // renumbered so that runs of RT_XCD_GROUP consecutive work items (neighbouring rays, which walk the
@@ -2062,6 +2346,23 @@ __device__ __forceinline__ uint32_t light_key(const LightProj& lp, rt_f3 pos) {
 #ifndef RT_WF_BLOCK
 #define RT_WF_BLOCK 64
 #endif
+// The record of a camera ray's sample: hit point, triangle, state and the light-space key of its shadow ray.
+__device__ __forceinline__ void primary_record(const SceneView& sv, const LightProj& lp, rt_f3 sun, bool inside, const HitD& h,
+                                               rt_f3 o, rt_f3 d, uint32_t slot, float4* __restrict__ samp,
+                                               uint32_t* __restrict__ state, uint32_t* __restrict__ keys) {
+    const bool hit_any = inside && h.tri != RT_MISS;
+    HitD hs = h;
+    if (!hit_any) hs.tri = 0, hs.obj = 0;
+    const Surface sf = surface_of(sv, hs, o, d);
+    const rt_f3 sun_dir = g_normalize(sun - sf.pos);
+    const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
+    samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(h.tri));
+    state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
+    // Light-space key: the hit point projected from the sun onto the plane across the light's
+    // dominant axis; points on one line to the sun get (nearly) one key.
+    keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
+}
+
 template <bool STATS, int BLOCK>
 __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv, DevRenderParams p, LightProj lp,
                                                       const uint32_t* __restrict__ tile_list,
@@ -2074,19 +2375,15 @@ __global__ __launch_bounds__(BLOCK, RT_WF_WAVES) void k_wf_primary(SceneView sv,
     LaneStats st;
     const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, pm.x, pm.y, pm.s);
     const rt_f3 sun = f3(p.sun[0], p.sun[1], p.sun[2]);
-    const HitD h = closest_all_packet<STATS>(sv, o, d, pm.inside, s_beam, st);
-    const bool hit_any = pm.inside && h.tri != RT_MISS;
-    HitD hs = h;
-    if (!hit_any) hs.tri = 0, hs.obj = 0;
-    const Surface sf = surface_of(sv, hs, o, d);
-    const rt_f3 sun_dir = g_normalize(sun - sf.pos);
-    const bool lit = hit_any && g_dot(sf.normal, sun_dir) > 0.0f;
+    const HitD h = closest_all_packet<STATS, true>(sv, o, d, pm.inside, s_beam, st);
     const uint32_t slot = pm.block * BLOCK + threadIdx.x;
-    samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(h.tri));
-    state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
-    // Light-space key: the hit point projected from the sun onto the plane across the light's
-    // dominant axis; points on one line to the sun get (nearly) one key.
-    keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
+    if (pm.inside && h.tri == RT_REDO) {
+        // left to k_wf_primary_redo
+        state[slot] = RT_ST_REDO;
+        keys[slot] = 0xFFFFFFFFu;
+    } else {
+        primary_record(sv, lp, sun, pm.inside, h, o, d, slot, samp, state, keys);
+    }
     if (STATS) flush_stats(st, stats);
 }
 
@@ -2780,7 +3077,12 @@ struct RasterTileLds {
     uint16_t segs[RT_RTILE_GROUP][64 * (RT_RTILE / RT_SEG)];   // per wave: row segments of the current 64 triangles: lane | segment << 6
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
     float idx[RT_RTILE], idy[RT_RTILE];          // their reciprocals, as Ray.inv_dir holds them (src/main.rs:329)
+    uint32_t tie[RT_RTILE * RT_RTILE / 32];      // one bit per sample: two accepted triangles within RT_TIE_ULPS of each other in t
 };
+// How near (in units of the last place of t) two accepted triangles of one sample have to lie for the
+// sample to be marked: only then can the order of the reference's search decide between them (see the
+// record loop of k_raster_tile).
+#define RT_TIE_ULPS 1024u
 // Orders a wave's own LDS writes before its later LDS reads (the hardware serves one wave's LDS
 // instructions in order; this keeps the compiler from moving them).
 __device__ __forceinline__ void wave_lds_sync() {
@@ -2891,6 +3193,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
 #endif
 
     for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE; i += 64u * RT_RTILE_GROUP) lds.z[i] = RT_ZKEY_NONE;
+    for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE / 32u; i += 64u * RT_RTILE_GROUP) lds.tie[i] = 0u;
     if (threadIdx.x < RT_RTILE) {
         const float c = tab[min(su0 + (int)threadIdx.x, gw - 1)];
         lds.dx[threadIdx.x] = c, lds.idx[threadIdx.x] = 1.0f / c;
@@ -2950,7 +3253,14 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                 if (STATS) st.box += 1, st.bytes += 16;
                 if (!raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + (zi & (RT_RTILE - 1u)), (uint32_t)sw0 + zi / RT_RTILE)) continue;
             }
-            atomicMin(&lds.z[zi], ((unsigned long long)__float_as_uint(ev.t) << 32) | id);
+            // The minimum so far comes back: whenever the new t and that one lie within RT_TIE_ULPS of each
+            // other the sample is marked. The minima of a sample only fall, so every accepted triangle that
+            // near the final minimum meets it, or a value between the two, in one of these exchanges ("none"
+            // has the largest bits of all and is near nothing).
+            const uint32_t tb = __float_as_uint(ev.t);
+            const unsigned long long was = atomicMin(&lds.z[zi], ((unsigned long long)tb << 32) | id);
+            const uint32_t ob = (uint32_t)(was >> 32);
+            if ((ob > tb ? ob - tb : tb - ob) <= RT_TIE_ULPS && (uint32_t)was != id) atomicOr(&lds.tie[zi >> 5], 1u << (zi & 31u));
         }
         wave_lds_sync();   // the next call lays its samples out over these
     };
@@ -3178,6 +3488,16 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         for (uint32_t u = 0; u < U; ++u) {
             const rt_f3 inv = f3(lds.idx[sul[u]], lds.idy[swl[u]], 1.0f);
             if (hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv, hs[u].t)) {
+                // A hit in the very plane of its leaf's box (an axis-aligned wall) fails this by rounding as
+                // often as not. The order matters only if another accepted triangle lies between the hit
+                // and the box's near plane: none does when the box passes with the ray cut RT_TIE_ULPS
+                // behind the hit and the sample is not marked.
+                const uint32_t zi = swl[u] * RT_RTILE + sul[u];
+                const float t_far = __uint_as_float(__float_as_uint(hs[u].t) + RT_TIE_ULPS);
+                if (!((lds.tie[zi >> 5] >> (zi & 31u)) & 1u) && ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv, t_far)) continue;
+#ifdef RT_NO_RESCAN
+                continue;
+#endif
                 const unsigned long long key = rescan(sul[u], swl[u]);
                 hit_any[u] = key != RT_ZKEY_NONE;
                 hs[u].tri = hit_any[u] ? (uint32_t)key : 0u;
@@ -3267,6 +3587,8 @@ __global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRende
     samp[slot] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(hit_any ? hs.tri : RT_MISS));
     state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
     keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
+    // a nearest hit whose place in the reference's order could matter is left to k_wf_primary_redo
+    if (hit_any && closest_needs_resolve(sv, hs.obj, o, g_recip(d), hs)) state[slot] = RT_ST_REDO, keys[slot] = 0xFFFFFFFFu;
     if (STATS) {
         LaneStats st;
         st.rays = pm.inside ? 1u : 0u;
@@ -3893,6 +4215,28 @@ struct SlotMap {
     }
 };
 
+// The samples k_wf_primary has left undecided (RT_ST_REDO), by the per-lane search with closest_resolve. A few
+// thousand waves go over all the slots' state words; a marked slot's pixel and sample come from its number.
+__global__ __launch_bounds__(64) void k_wf_primary_redo(SceneView sv, DevRenderParams p, LightProj lp,
+                                                        const uint32_t* __restrict__ tile_list, uint32_t n_slots,
+                                                        float4* __restrict__ samp, uint32_t* __restrict__ state,
+                                                        uint32_t* __restrict__ keys) {
+    using Stack = LaneStackT<RT_STACK_LDS, 64>;
+    __shared__ uint2 s_stack[RT_STACK_LDS * 64];
+    uint2 stack_rest[Stack::REST];
+    Stack stk;
+    stk.lds = &s_stack[threadIdx.x];
+    stk.spill = stack_rest;
+    LaneStats st;
+    for (uint32_t slot = blockIdx.x * 64u + threadIdx.x; slot < n_slots; slot += gridDim.x * 64u) {
+        if (state[slot] != RT_ST_REDO) continue;
+        const SlotMap sm(p, tile_list, slot);
+        const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, sm.x, sm.y, sm.s);
+        const HitD h = closest_all<false>(sv, o, d, stk, st);
+        primary_record(sv, lp, f3(p.sun[0], p.sun[1], p.sun[2]), true, h, o, d, slot, samp, state, keys);
+    }
+}
+
 // Mirror direction of src/main.rs:245.
 __device__ __forceinline__ rt_f3 reflect_dir(rt_f3 d, rt_f3 n) { return d - 2.0f * n * g_dot(d, n); }
 
@@ -3952,12 +4296,16 @@ struct TreeSource {
         }
         return true;
     }
+    __device__ __forceinline__ bool marked(uint32_t idx) const {
+        const uint32_t j = level ? queue[idx] : idx;
+        return dstate[(size_t)level * tr.level_rays + j] == RT_ST_REDO;
+    }
     __device__ __forceinline__ void emit(uint32_t idx, const HitD& h, rt_f3 o, rt_f3 d) const {
         const uint32_t j = level ? queue[idx] : idx;
         const size_t i = (size_t)level * tr.level_rays + j;
         bool spawn = false;
-        if (h.tri == RT_MISS) {
-            dstate[i] = 0u;
+        if (h.tri == RT_MISS || h.tri == RT_REDO) {
+            dstate[i] = h.tri == RT_REDO ? RT_ST_REDO : 0u;   // (RT_ST_REDO: k_wf_bounce_redo takes the ray up again)
             dkeys[i] = 0xFFFFFFFFu;
         } else {
             const Surface s2 = surface_of(sv, h, o, d);
@@ -4028,6 +4376,23 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
         printf("k_wf_bounce block %u of %u: start %lld end %lld wall ticks (100 MHz), %lld shader ticks\n", blockIdx.x, gridDim.x, w0 % 100000000ll, wall_clock64() % 100000000ll, clock64() - c0);
 #endif
     if (STATS) flush_stats(st, stats);
+}
+
+// The rays of a level that k_wf_bounce has left undecided (RT_ST_REDO).
+__global__ __launch_bounds__(64) void k_wf_bounce_redo(SceneView sv, DevRenderParams p, LightProj lp, RayTree tr,
+                                                       uint32_t level, const uint32_t* __restrict__ tile_list,
+                                                       const float4* __restrict__ samp, const uint32_t* __restrict__ state,
+                                                       float4* dsamp, uint32_t* dstate, uint32_t* __restrict__ dkeys,
+                                                       uint32_t* queues, uint32_t* counts) {
+    __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
+    if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
+    const bool last = level + 1 >= tr.levels;
+    const uint32_t n = level ? counts[level] : tr.level_rays;
+    const TreeSource src{sv, p, lp, tr, level, tile_list, samp, state, dsamp, dstate, dkeys,
+                         queues + (size_t)level * tr.level_rays,
+                         last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
+                         last ? nullptr : counts + level + 1, s_q};
+    redo_marked(sv, n, src);
 }
 
 // Sun light at a stored hit, src/main.rs:176-241, from its record.
@@ -4173,15 +4538,20 @@ hipError_t trace_closest(const SceneView& sv, const rt_ray* d_rays, uint64_t n, 
                          char how, hipStream_t s) {
     if (n == 0) return hipSuccess;
     // how = 'l': one ray per lane to the end; 'w': wave-coherent walks; otherwise the persistent per-lane walk.
-    const int walk = how == 'l' ? 1 : (how == 'w' ? 2 : 0);
-    if (walk == 0 && d_counter && n < (1ull << 32) - RT_WALK_HEADROOM)
+    // (the first two leave the rare ray whose answer hangs on the reference's order to k_trace_closest_redo)
+    const bool fits = n < (1ull << 32) - RT_WALK_HEADROOM;
+    const int walk = how == 'l' || !fits ? 1 : (how == 'w' ? 2 : 0);
+    if (walk == 0 && d_counter)
         hipLaunchKernelGGL(k_trace_closest_persistent, dim3(persistent_grid(n)), dim3(64), 0, s, sv, d_rays, (uint32_t)n,
                            d_counter, d_out);
     else if (walk == 2)
         hipLaunchKernelGGL(k_trace_closest_wave, dim3(grid_for(n, 64)), dim3(64), (size_t)RT_BEAM_LEVELS * 64 * 8, s, sv,
                            d_rays, n, (uint32_t)RT_BEAM_LEVELS, d_out);
-    else
+    else {
         hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, RT_BLOCK)), dim3(RT_BLOCK), 0, s, sv, d_rays, n, d_out);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_trace_closest_redo, dim3(std::min(grid_for(n, 64), 4096u)), dim3(64), 0, s, sv, d_rays, (uint32_t)n, d_out);
     return hipGetLastError();
 }
 
@@ -4267,6 +4637,8 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
     else
         hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_stats);
+    hipLaunchKernelGGL(k_wf_primary_redo, dim3(std::min(blocks, 4096u)), dim3(64), 0, s, sv, p, lp, d_tile_list,
+                       blocks * RT_WF_BLOCK, d_samp, d_state, d_keys);
     return hipGetLastError();
 }
 
@@ -4336,6 +4708,8 @@ hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const L
     else
         hipLaunchKernelGGL((k_raster_records<false, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, lp, d_tile_list,
                            d_zbuf, d_samp, d_state, d_keys, d_stats);
+    hipLaunchKernelGGL(k_wf_primary_redo, dim3(std::min(blocks, 4096u)), dim3(64), 0, s, sv, p, lp, d_tile_list,
+                       blocks * RT_BLOCK, d_samp, d_state, d_keys);
     return hipGetLastError();
 }
 
@@ -4429,6 +4803,8 @@ hipError_t wf_bounce(const SceneView& sv, const DevRenderParams& p, const LightP
     else
         hipLaunchKernelGGL((k_wf_bounce<false>), grid, dim3(64), 0, s, sv, p, lp, tr, level, d_tile_list, d_counter,
                            d_samp, d_state, d_dsamp, d_dstate, d_dkeys, d_queues, d_counts, d_stats);
+    hipLaunchKernelGGL(k_wf_bounce_redo, dim3(4096), dim3(64), 0, s, sv, p, lp, tr, level, d_tile_list, d_samp, d_state,
+                       d_dsamp, d_dstate, d_dkeys, d_queues, d_counts);
     return hipGetLastError();
 }
 
