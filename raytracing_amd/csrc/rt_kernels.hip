@@ -45,11 +45,12 @@ __device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2
 // (src/main.rs:134-136). A triangle test that rounds badly (a needle whose determinant cancels) can
 // accept a ray that passes the leaf's box by a thousandth of its size, which the reference never
 // tests; the searches here reach triangles by other routes (a tree of their own boxes, projection,
-// light-space cells), so a hit they are about to accept is put through this gate first. The ray
-// length is +inf, as the shadow search passes it (src/main.rs:185); the nearest-hit search passes the
-// nearest distance of the moment (src/main.rs:98,127), which can only cull a leaf whose entry distance
-// lies beyond a hit already found -- a triangle in it that still computes a nearer t (its t rounded to
-// before its own box) while an earlier triangle lies in between is the one case left out.
+// light-space cells), so a hit they are about to accept is put through this gate first. The shadow
+// search passes +inf for the ray's length (src/main.rs:185); the nearest-hit search passes the nearest
+// distance of the moment (src/main.rs:98,127), which makes its answer depend on the order of the
+// search where two triangles lie within rounding of each other: the nearest-hit searches here test
+// their winner with the ray cut at the winner's own distance and play the reference's order back where
+// that fails (closest_needs_resolve and closest_resolve below; the record loop of k_raster_tile).
 // `ob` is the triangle's object, `id` its global number (not a trailing triangle).
 // lo4, hi4: the leaf's entry of SceneView::leaf_gate (its box, and which of the two tests it takes).
 __device__ __forceinline__ bool ref_leaf_gate(float4 lo4, float4 hi4, rt_f3 o, rt_f3 inv, float ray_length = RT_INF) {
@@ -388,7 +389,7 @@ __device__ __forceinline__ float packed_box_entry(rt_f3 bmin, rt_f3 bmax, rt_f3 
 }
 
 #define RT_RESOLVE_MAX 8
-#define RT_RESOLVE_STACK 40    // up to three children left waiting per level of a tree; a deeper one goes to the last resort
+#define RT_RESOLVE_STACK 96    // up to three children left waiting per level of a tree; a deeper one goes to the last resort
 struct NearList {
     uint32_t n;
     uint32_t ids[RT_RESOLVE_MAX];
@@ -3071,14 +3072,20 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ coun
 #endif
 struct RasterTileLds {
     unsigned long long z[RT_RTILE * RT_RTILE];   // nearest (t, id) per sample of the tile, row by row
-    float tri[RT_RTILE_GROUP][RT_RTILE_TRIS][12];    // per wave: e1 xyz, e2 xyz, v0 xyz, id, object word, -
+    float tri[RT_RTILE_GROUP][RT_RTILE_TRIS][12];    // per wave: e1 xyz, e2 xyz, v0 xyz, id, object word, a word of tie bits
     uint32_t queue[RT_RTILE_GROUP][RT_RASTER_QUEUE]; // per wave: runs of candidate samples: first sample | length << 10 | slot << 16
     uint16_t samples[RT_RTILE_GROUP][64 * RT_RUN];   // per wave: the samples of up to 64 runs, packed: sample | slot << 10
     uint16_t segs[RT_RTILE_GROUP][64 * (RT_RTILE / RT_SEG)];   // per wave: row segments of the current 64 triangles: lane | segment << 6
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
     float idx[RT_RTILE], idy[RT_RTILE];          // their reciprocals, as Ray.inv_dir holds them (src/main.rs:329)
-    uint32_t tie[RT_RTILE * RT_RTILE / 32];      // one bit per sample: two accepted triangles within RT_TIE_ULPS of each other in t
+    // Tie bits, one per sample: two accepted triangles within RT_TIE_ULPS of each other in t. They live in
+    // the twelfth word of the triangle slots (an array of their own took the structure past a multiple
+    // of the 1,280 bytes LDS is handed out in, and the kernel from ten groups a CU to nine: 0.07 ms a frame).
+    __device__ __forceinline__ uint32_t* tie_word(uint32_t w) {
+        return reinterpret_cast<uint32_t*>(&tri[w / RT_RTILE_TRIS][w % RT_RTILE_TRIS][11]);
+    }
 };
+static_assert(RT_RTILE * RT_RTILE / 32 <= RT_RTILE_GROUP * RT_RTILE_TRIS, "a tie word per triangle slot covers the tile's samples");
 // How near (in units of the last place of t) two accepted triangles of one sample have to lie for the
 // sample to be marked: only then can the order of the reference's search decide between them (see the
 // record loop of k_raster_tile).
@@ -3193,7 +3200,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
 #endif
 
     for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE; i += 64u * RT_RTILE_GROUP) lds.z[i] = RT_ZKEY_NONE;
-    for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE / 32u; i += 64u * RT_RTILE_GROUP) lds.tie[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE / 32u; i += 64u * RT_RTILE_GROUP) *lds.tie_word(i) = 0u;
     if (threadIdx.x < RT_RTILE) {
         const float c = tab[min(su0 + (int)threadIdx.x, gw - 1)];
         lds.dx[threadIdx.x] = c, lds.idx[threadIdx.x] = 1.0f / c;
@@ -3253,14 +3260,17 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                 if (STATS) st.box += 1, st.bytes += 16;
                 if (!raster_object_box(sv, tab, L, gw, ow, (uint32_t)su0 + (zi & (RT_RTILE - 1u)), (uint32_t)sw0 + zi / RT_RTILE)) continue;
             }
-            // The minimum so far comes back: whenever the new t and that one lie within RT_TIE_ULPS of each
-            // other the sample is marked. The minima of a sample only fall, so every accepted triangle that
-            // near the final minimum meets it, or a value between the two, in one of these exchanges ("none"
-            // has the largest bits of all and is near nothing).
+            // The minimum so far comes back from the exchange: whenever the new t and that one lie within
+            // RT_TIE_ULPS of each other the sample is marked. The minima of a sample only fall, so every accepted
+            // triangle that near the final minimum meets it, or a value between the two, in one of these
+            // exchanges ("none" has the largest bits of all and is near nothing; a triangle that meets its own
+            // earlier entry, from a run tested twice, is no tie).
             const uint32_t tb = __float_as_uint(ev.t);
-            const unsigned long long was = atomicMin(&lds.z[zi], ((unsigned long long)tb << 32) | id);
-            const uint32_t ob = (uint32_t)(was >> 32);
-            if ((ob > tb ? ob - tb : tb - ob) <= RT_TIE_ULPS && (uint32_t)was != id) atomicOr(&lds.tie[zi >> 5], 1u << (zi & 31u));
+            const unsigned long long key = ((unsigned long long)tb << 32) | id;
+            const unsigned long long was = atomicMin(&lds.z[zi], key);
+            uint32_t apart;   // |was.t - t| in units of the last place
+            asm("v_sad_u32 %0, %1, %2, 0" : "=v"(apart) : "v"((uint32_t)(was >> 32)), "v"(tb));
+            if (apart <= RT_TIE_ULPS && was != key) atomicOr(lds.tie_word(zi >> 5), 1u << (zi & 31u));
         }
         wave_lds_sync();   // the next call lays its samples out over these
     };
@@ -3494,10 +3504,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
                 // behind the hit and the sample is not marked.
                 const uint32_t zi = swl[u] * RT_RTILE + sul[u];
                 const float t_far = __uint_as_float(__float_as_uint(hs[u].t) + RT_TIE_ULPS);
-                if (!((lds.tie[zi >> 5] >> (zi & 31u)) & 1u) && ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv, t_far)) continue;
-#ifdef RT_NO_RESCAN
-                continue;
-#endif
+                if (!((*lds.tie_word(zi >> 5) >> (zi & 31u)) & 1u) && ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv, t_far)) continue;
                 const unsigned long long key = rescan(sul[u], swl[u]);
                 hit_any[u] = key != RT_ZKEY_NONE;
                 hs[u].tri = hit_any[u] ? (uint32_t)key : 0u;

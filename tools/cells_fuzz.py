@@ -7,7 +7,11 @@ pixel or a hit id, the CPU oracle renders the frame and decides. A scene counts 
 or the cells differ from the oracle; a tree walk that differs from the oracle (it reaches a triangle
 through the triangle's own box, the reference through the box of its leaf of eight, and a triangle test
 that rounds badly can tell the two apart) is reported by itself.
-usage: [FUZZ_LARGE=1|medium] [FUZZ_W=640 FUZZ_H=360] python tools/cells_fuzz.py [rounds] [first seed]"""
+FUZZ_ORACLE=1 has the oracle render every scene, not only those whose paths differ (the paths share
+the rule by which they confirm a nearest hit, so their agreeing proves less than the oracle's does);
+FUZZ_SPLIT=1 cuts the soup into three objects, two of them with trailing n % 8 triangles (=2: the last
+one only, which projection accepts).
+usage: [FUZZ_LARGE=1|medium] [FUZZ_ORACLE=1] [FUZZ_SPLIT=1] [FUZZ_W=640 FUZZ_H=360] python tools/cells_fuzz.py [rounds] [first seed]"""
 import os
 import sys
 
@@ -61,6 +65,13 @@ def scene_of(rng, sun):
     a = c - (e1 + e2) / 3.0
     v = np.stack([a, a + e1, a + e2], axis=1).astype(np.float32)
     v[..., 2] = np.maximum(v[..., 2], 0.5)
+    if os.environ.get("FUZZ_SPLIT") == "2":    # only the last object has trailing triangles: projection takes such scenes
+        a = n // 3 - (n // 3) % 8
+        return [as_object(v[:a]), as_object(v[a:2 * a]), as_object(v[2 * a:n - 3])]
+    if os.environ.get("FUZZ_SPLIT"):
+        a = n // 3 + 3 - (n // 3) % 8          # 3 trailing triangles
+        b = a + n // 3 + 5 - (n // 3) % 8      # 5 trailing triangles
+        return [as_object(v[:a]), as_object(v[a:b]), as_object(v[b:])]
     return [as_object(v)]
 
 
@@ -97,7 +108,7 @@ def main():
         took += int(st["shadow_by_cells"])
         projected += int(st["camera_by_projection"])
         verdict = ""
-        if diff != 0 or id_diff != 0 or not np.array_equal(b, c):
+        if diff != 0 or id_diff != 0 or not np.array_equal(b, c) or os.environ.get("FUZZ_ORACLE"):
             from oracle import oracle_ffi
             o = oracle_ffi.OracleScene(objs)
             ref, ref_ids, _ = o.render(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun, want_hit_ids=True)
