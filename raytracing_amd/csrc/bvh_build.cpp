@@ -2,6 +2,7 @@
 // nodes laid out in depth-first order. Host code; runs once per scene.
 
 #include "bvh_build.h"
+#include "rt_device.h"
 
 #include <algorithm>
 #include <atomic>
@@ -23,7 +24,10 @@ constexpr int BINS = 16;
 // could accept; for origins much farther away than that the rounding of origin * 1 / direction
 // grows with the origin and a grazing hit at a box edge can be missed (a documented edge class).
 constexpr float PAD_REL = 6e-6f;
-constexpr float PAD_ABS = 1e-6f;
+// PAD_ABS is ten times what those roundings need: the nearest-hit walks rely on reaching every triangle
+// whose hit lies less than half the padding (as a distance along the ray) behind the nearest one (tie_note
+// in rt_kernels.hip, which reads the same constant).
+constexpr float PAD_ABS = RT_PAD_ABS;   // rt_device.h
 
 // Tuning knobs (environment, read once): largest leaf and the price of one traversal step in
 // triangle tests.

@@ -34,7 +34,21 @@ struct HitD {
     uint32_t obj;
     float t, u, v;
     float closest;
+    bool tie;   // the current object's walk has met two accepted triangles within RT_TIE_WALK ulps of each other (tie_note)
 };
+// Walks note when an accepted triangle's t lies within RT_TIE_WALK units of the last place of the nearest
+// distance of that moment, on either side (+inf, the distance before any hit, is near nothing). The nearest
+// distance only falls, so every accepted triangle that near the final one meets it, or a value between the
+// two, in one of these comparisons -- if the walk tests it at all. The trees' boxes are padded by
+// RT_PAD_ABS of the object's largest coordinate (PAD_ABS of the builders), so a triangle whose hit lies less
+// than pad / |d| behind the nearest one is never culled: its box begins that much before its hit along
+// whichever axis it is entered by. closest_needs_resolve relies on half of that.
+#define RT_TIE_WALK 1024u
+__device__ __forceinline__ void tie_note(float t, float closest, bool accepted, bool& tie) {
+    uint32_t apart;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(apart) : "v"(__float_as_uint(t)), "v"(__float_as_uint(closest)));
+    tie = tie || (accepted && apart <= RT_TIE_WALK);
+}
 
 __device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
@@ -236,6 +250,7 @@ __device__ __forceinline__ bool record_test(float4 ra, float4 rb, float4 rc, uin
     const uint32_t id = __float_as_uint(rc.y);
     const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
     if (ANY) return !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t);
+    tie_note(ev.t, closest, !ev.failed && ev.t > 0.0f, hit.tie);
     const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
     if (!ev.failed && ev.t > 0.0f && better) {
         closest = ev.t;
@@ -269,6 +284,7 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
                                            LaneStats& st) {
     const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
     uint32_t local_best = 0;
+    hit.tie = false;
     stk.sp = 0;
     uint32_t cur = root;
     for (;;) {
@@ -309,10 +325,30 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
 // closest_needs_resolve is the test, run once per ray and object that found a hit; closest_resolve plays
 // the reference back for the (rare) rays that fail it.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool closest_needs_resolve(const SceneView& sv, uint32_t oi, rt_f3 o, rt_f3 inv, const HitD& hit) {
+// Half the hits on an axis-aligned wall fail the first test by rounding alone. Nothing can differ for them
+// unless a second accepted triangle lies between the hit and the entry distance of its leaf's box: none does
+// when the walk has noted no tie (hit.tie, tie_note) and the box passes with the ray cut RT_TIE_WALK ulps
+// behind the hit.
+// (tri_base, leaf_base: the object's, which the callers hold already: one read fewer ahead of the gate's)
+__device__ __forceinline__ bool closest_needs_resolve(const SceneView& sv, uint32_t oi, uint32_t tri_base, uint32_t leaf_base, rt_f3 o,
+                                                      rt_f3 d, rt_f3 inv, const HitD& hit) {
+    const float4* lg = sv.leaf_gate + 2 * (size_t)(leaf_base + ((hit.tri - tri_base) >> 3));
+    const float4 lo4 = lg[0], hi4 = lg[1];
+    if (ref_leaf_gate(lo4, hi4, o, inv, hit.t)) return false;
+    if (hit.tie) return true;
     const DevObject& ob = sv.objs[oi];
-    const float4* lg = sv.leaf_gate + 2 * (size_t)(ob.leaf_base + ((hit.tri - ob.tri_base) >> 3));
-    return !ref_leaf_gate(lg[0], lg[1], o, inv, hit.t);
+    // how far behind the hit the walk is sure to have tested everything: half the boxes' padding, as a distance
+    // along the ray, and no farther than the ties are noted
+    float largest = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) largest = fmaxf(largest, fmaxf(__builtin_fabsf(ob.bbmin[k]), __builtin_fabsf(ob.bbmax[k])));
+    const float sure = 0.5f * RT_PAD_ABS * largest / __builtin_sqrtf(g_dot(d, d));
+    const float t_far = fminf(hit.t + sure, __uint_as_float(__float_as_uint(hit.t) + RT_TIE_WALK));
+    return !ref_leaf_gate(lo4, hi4, o, inv, t_far);
+}
+__device__ __forceinline__ bool closest_needs_resolve(const SceneView& sv, uint32_t oi, rt_f3 o, rt_f3 d, rt_f3 inv, const HitD& hit) {
+    const DevObject& ob = sv.objs[oi];
+    return closest_needs_resolve(sv, oi, ob.tri_base, ob.leaf_base, o, d, inv, hit);
 }
 
 // These run for one ray in many thousands and are called, not inlined: a called function's registers count
@@ -456,10 +492,66 @@ __device__ __noinline__ bool collect_near(const SceneView& sv, uint32_t root, co
 // same answer for every such value unless its own entry distance lies above `far`, and then, or when
 // there are too many to collect, or when none of the collected ones is accepted, the reference's search
 // is run as it stands (ref_search_upto).
-// (in three called parts, so that none of them holds much across a call)
 __device__ __forceinline__ const float4* resolve_gate_of(const SceneView& sv, const DevObject& ob, uint32_t id) {
     return sv.leaf_gate + 2 * (size_t)(ob.leaf_base + ((id - ob.tri_base) >> 3));
 }
+// The nearest hit of object oi among the triangles whose leaf the reference opens at all for this ray (the
+// gate with the ray's length at +inf), nearer than `before`: what a walk's answer should have been when its
+// winner sits in a leaf that is closed to the ray (a needle whose test rounds badly, a hit on the very edge
+// of a wall). The least (t, id) as the walks take it, ties noted as they note them; a child at a time,
+// as in collect_near. False when the tree is too deep for the stack.
+__device__ __noinline__ bool gated_nearest(const SceneView& sv, uint32_t oi, float before, ResolveRay& r) {
+    const DevObject& ob = sv.objs[oi];
+    uint32_t stack[RT_RESOLVE_STACK];
+    uint32_t sp = 0, best = RT_MISS;
+    uint32_t cur = ob.root;
+    const rt_f3 o = r.o, d = r.d, inv = g_recip(d);
+    float closest = before;
+    bool tie = false;
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const float4 A = np[2 * k], B = np[2 * k + 1];
+                const uint32_t c = __float_as_uint(B.z);
+                if (c == EMPTY) continue;
+                const float ax = (A.x - o.x) * inv.x, bx = (A.w - o.x) * inv.x;
+                const float ay = (A.y - o.y) * inv.y, by = (B.x - o.y) * inv.y;
+                const float az = (A.z - o.z) * inv.z, bz = (B.y - o.z) * inv.z;
+                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), closest));
+                if (tn <= tf * 1.00001f + 1e-30f) {
+                    if (sp == RT_RESOLVE_STACK) return false;
+                    stack[sp++] = c;
+                }
+            }
+        } else {
+            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = (cur & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4* rec = sv.recs + 3 * (size_t)(first + i);
+                const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                const rt_tri_eval ev = tri_intersect(f3(ra.w, rb.x, rb.y), f3(rb.z, rb.w, rc.x), f3(ra.x, ra.y, ra.z), o, d);
+                if (ev.failed || !(ev.t > 0.0f)) continue;
+                const uint32_t id = __float_as_uint(rc.y);
+                const float4* lg = resolve_gate_of(sv, ob, id);
+                if (!ref_leaf_gate(lg[0], lg[1], o, inv)) continue;
+                tie_note(ev.t, closest, true, tie);
+                if (ev.t < closest || (ev.t == closest && best != RT_MISS && id < best)) {
+                    closest = ev.t, best = id;
+                    r.hit.tri = id, r.hit.obj = oi, r.hit.t = ev.t, r.hit.u = ev.u, r.hit.v = ev.v;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    r.hit.tie = tie;
+    r.closest = closest;
+    if (best == RT_MISS) r.hit.tri = RT_MISS;
+    return true;
+}
+
+// (in three called parts, so that none of them holds much across a call)
 // `far` for the hit in r; NaN when the reference never looks into W's leaf (its answer may then lie anywhere behind W).
 __device__ __noinline__ float resolve_far(const SceneView& sv, uint32_t oi, const ResolveRay& r) {
     const DevObject& ob = sv.objs[oi];
@@ -499,8 +591,18 @@ __device__ __noinline__ bool resolve_replay(const SceneView& sv, uint32_t oi, fl
     return true;
 }
 __device__ __noinline__ void closest_resolve(const SceneView& sv, uint32_t oi, float before, ResolveRay& r) {
-    const float far = resolve_far(sv, oi, r);
+    float far = resolve_far(sv, oi, r);
     bool done = false;
+    if (far != far && oi == 0u) {
+        // W's leaf is closed to the ray. In the first object (nothing before it to fall back on) the search is
+        // done over without such triangles; its winner is then looked at as any walk's is.
+        if (gated_nearest(sv, oi, before, r)) {
+            if (r.hit.tri == RT_MISS) return;
+            const rt_f3 inv = g_recip(r.d);
+            if (!closest_needs_resolve(sv, oi, r.o, r.d, inv, r.hit)) return;
+            far = resolve_far(sv, oi, r);
+        }
+    }
     if (far == far) {
         NearList near;
         near.n = 0;
@@ -511,7 +613,7 @@ __device__ __noinline__ void closest_resolve(const SceneView& sv, uint32_t oi, f
 // The call, from a walk that has just ended object oi's tree with a nearer hit than `before`.
 __device__ __forceinline__ void closest_confirm(const SceneView& sv, uint32_t oi, rt_f3 o, rt_f3 d, rt_f3 inv, float before,
                                                 HitD& hit, float& closest) {
-    if (!closest_needs_resolve(sv, oi, o, inv, hit)) return;
+    if (!closest_needs_resolve(sv, oi, o, d, inv, hit)) return;
     ResolveRay r;
     r.o = o, r.d = d, r.closest = closest, r.hit = hit;
     closest_resolve(sv, oi, before, r);
@@ -669,8 +771,11 @@ __device__ __forceinline__ void packet_tri(const f32x8_t ra, const f32x4_t rb, u
             }
         } else {
             const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
+            const bool accepted = pred && !ev.failed && ev.t > 0.0f;
+            // (most triangles a wave fetches are accepted by none of its rays: one scalar branch skips the note)
+            if (__ballot(accepted) != 0ull) tie_note(ev.t, closest, accepted, hit.tie);
             const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
-            if (pred && !ev.failed && ev.t > 0.0f && better) {
+            if (accepted && better) {
                 closest = ev.t;
                 local_best = id;
                 hit.tri = id;
@@ -743,6 +848,7 @@ __device__ __forceinline__ void packet_search(const SceneView& sv, uint32_t root
     const int lane = (int)(threadIdx.x & 63u);
     const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
     uint32_t local_best = 0;
+    hit.tie = false;
     WaveStack stk;
     uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)root);
     for (;;) {
@@ -1039,6 +1145,7 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     const uint32_t lane = threadIdx.x & 63u;
     if (STATS && lane == 0) st.walks[0] += 1;
     uint32_t local_best = 0;
+    hit.tie = false;
     // Farthest useful w per lane, relative to wbase: where the ray's current nearest hit lies.
     auto far_rel = [&](float c) {
         const float z = __builtin_fmaf(c, bl.dw, bl.ow);
@@ -1192,7 +1299,7 @@ __device__ __forceinline__ HitD closest_all_packet(const SceneView& sv, rt_f3 o,
             if (!beam_try<false, STATS>(sv, wide_root, oi, o, d, in_obj, closest, h, unused, beam_lds, st))
                 packet_search<false, STATS>(sv, root, oi, o, d, inv, in_obj, closest, h, unused, st);
             if (closest < before) {
-                if (DEFER) redo = redo || closest_needs_resolve(sv, oi, o, inv, h);
+                if (DEFER) redo = redo || closest_needs_resolve(sv, oi, tri_base, __float_as_uint(ob[15]), o, d, inv, h);
                 else closest_confirm(sv, oi, o, d, inv, before, h, closest);
             }
         }
@@ -1532,7 +1639,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                 // hit.obj == oi says so) whose answer may depend on the reference's order ends the ray here
                 // with RT_REDO for a result: the kernel that follows the walk decides it.
                 bool redo = false;
-                if (!ANY && hit.tri != RT_MISS && hit.obj == oi) redo = closest_needs_resolve(sv, oi, o, inv, hit);
+                if (!ANY && hit.tri != RT_MISS && hit.obj == oi) redo = closest_needs_resolve(sv, oi, ob.tri_base, ob.leaf_base, o, d, inv, hit);
                 if (redo) hit.tri = RT_REDO, oi = sv.n_objs;
                 for (uint32_t r = 0; !redo && r < ob.n_rest; ++r) {
                     const float* pv = sv.rest_verts + 9 * (size_t)(ob.rest_base + r);
@@ -1570,6 +1677,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                     walking = true;
                     cur = root;
                     local_best = 0;
+                    hit.tie = false;
                     stk.reset();
                 }
             } else {
@@ -3595,7 +3703,8 @@ __global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRende
     state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
     keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
     // a nearest hit whose place in the reference's order could matter is left to k_wf_primary_redo
-    if (hit_any && closest_needs_resolve(sv, hs.obj, o, g_recip(d), hs)) state[slot] = RT_ST_REDO, keys[slot] = 0xFFFFFFFFu;
+    hs.tie = true;   // (nothing is known of the other triangles at this sample)
+    if (hit_any && closest_needs_resolve(sv, hs.obj, o, d, g_recip(d), hs)) state[slot] = RT_ST_REDO, keys[slot] = 0xFFFFFFFFu;
     if (STATS) {
         LaneStats st;
         st.rays = pm.inside ? 1u : 0u;
@@ -4235,12 +4344,19 @@ __global__ __launch_bounds__(64) void k_wf_primary_redo(SceneView sv, DevRenderP
     stk.lds = &s_stack[threadIdx.x];
     stk.spill = stack_rest;
     LaneStats st;
-    for (uint32_t slot = blockIdx.x * 64u + threadIdx.x; slot < n_slots; slot += gridDim.x * 64u) {
-        if (state[slot] != RT_ST_REDO) continue;
-        const SlotMap sm(p, tile_list, slot);
-        const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, sm.x, sm.y, sm.s);
-        const HitD h = closest_all<false>(sv, o, d, stk, st);
-        primary_record(sv, lp, f3(p.sun[0], p.sun[1], p.sun[2]), true, h, o, d, slot, samp, state, keys);
+    // four state words a lane and turn (n_slots is a multiple of 1,024: whole tiles)
+    for (uint32_t s4 = (blockIdx.x * 64u + threadIdx.x) * 4u; s4 < n_slots; s4 += gridDim.x * 256u) {
+        const uint4 w = *reinterpret_cast<const uint4*>(state + s4);
+        if (w.x != RT_ST_REDO && w.y != RT_ST_REDO && w.z != RT_ST_REDO && w.w != RT_ST_REDO) continue;
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (ws[k] != RT_ST_REDO) continue;
+            const uint32_t slot = s4 + k;
+            const SlotMap sm(p, tile_list, slot);
+            const rt_f3 o = f3(0.0f, 0.0f, 0.0f), d = camera_dir(p, sm.x, sm.y, sm.s);
+            const HitD h = closest_all<false>(sv, o, d, stk, st);
+            primary_record(sv, lp, f3(p.sun[0], p.sun[1], p.sun[2]), true, h, o, d, slot, samp, state, keys);
+        }
     }
 }
 
@@ -4644,8 +4760,8 @@ hipError_t wf_primary(const SceneView& sv, const DevRenderParams& p, const Light
     else
         hipLaunchKernelGGL((k_wf_primary<false, RT_WF_BLOCK>), dim3(xcd_grid(blocks)), dim3(RT_WF_BLOCK), lds, s, sv, p, lp, d_tile_list,
                            d_samp, d_state, d_keys, d_stats);
-    hipLaunchKernelGGL(k_wf_primary_redo, dim3(std::min(blocks, 4096u)), dim3(64), 0, s, sv, p, lp, d_tile_list,
-                       blocks * RT_WF_BLOCK, d_samp, d_state, d_keys);
+    hipLaunchKernelGGL(k_wf_primary_redo, dim3(std::min((blocks * RT_WF_BLOCK + 255u) / 256u, 8192u)), dim3(64), 0, s, sv, p, lp,
+                       d_tile_list, blocks * RT_WF_BLOCK, d_samp, d_state, d_keys);
     return hipGetLastError();
 }
 
@@ -4715,8 +4831,8 @@ hipError_t raster_records(const SceneView& sv, const DevRenderParams& p, const L
     else
         hipLaunchKernelGGL((k_raster_records<false, RT_BLOCK>), dim3(blocks), dim3(RT_BLOCK), 0, s, sv, p, lp, d_tile_list,
                            d_zbuf, d_samp, d_state, d_keys, d_stats);
-    hipLaunchKernelGGL(k_wf_primary_redo, dim3(std::min(blocks, 4096u)), dim3(64), 0, s, sv, p, lp, d_tile_list,
-                       blocks * RT_BLOCK, d_samp, d_state, d_keys);
+    hipLaunchKernelGGL(k_wf_primary_redo, dim3(std::min((blocks * RT_BLOCK + 255u) / 256u, 8192u)), dim3(64), 0, s, sv, p, lp,
+                       d_tile_list, blocks * RT_BLOCK, d_samp, d_state, d_keys);
     return hipGetLastError();
 }
 

@@ -31,7 +31,10 @@ namespace {
 // Widening of every triangle box, as in the host build: relative to the box's own coordinates plus
 // an absolute part tied to the object's largest coordinate (see bvh_build.cpp).
 constexpr float PAD_REL = 6e-6f;
-constexpr float PAD_ABS = 1e-6f;
+// PAD_ABS is ten times what those roundings need: the nearest-hit walks rely on reaching every triangle
+// whose hit lies less than half the padding (as a distance along the ray) behind the nearest one (tie_note
+// in rt_kernels.hip, which reads the same constant).
+constexpr float PAD_ABS = RT_PAD_ABS;   // rt_device.h
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {
     v &= 0x3FFu;

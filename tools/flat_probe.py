@@ -2,7 +2,7 @@
 """Camera-phase time of frames full of axis-aligned flat geometry (a tessellated wall facing the camera,
 a room of such walls), where a hit lies in the very plane of its leaf's box and the box test with the
 ray cut at the hit can round either way.
-usage: [RAYS_HIP_LIB=..] python tools/flat_probe.py [label]"""
+usage: [RAYS_HIP_LIB=..] [FLAT_WALK=1] python tools/flat_probe.py [label]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -51,6 +51,9 @@ def ms(a, b):
 
 label = sys.argv[1] if len(sys.argv) > 1 else ""
 os.environ["RAYS_HIP_RASTER_RATIO"] = "1e9"
+if os.environ.get("FLAT_WALK"):       # the same frames with every ray by tree walk
+    os.environ["RAYS_HIP_RASTER"] = "0"
+    os.environ["RAYS_HIP_SHADOW"] = "walk"
 ctx = Context(0)
 for which in ("wall", "tilted", "room"):
     scene = Scene(ctx, scene_of(which))
