@@ -175,6 +175,42 @@ def test_coplanar_layers_follow_the_order_of_the_reference_search(ctx, oracle, m
         o.close()
 
 
+def test_axis_aligned_room_every_search_equals_the_oracle(ctx, oracle, monkeypatch):
+    """Five tessellated axis-aligned walls (tools/flat_probe.py): every hit lies in the very plane of its
+    leaf's box, a fifth of them fail the box test with the ray cut at the hit by an ulp or two, and rays
+    along the walls' edges hit triangles whose leaves are closed to them. All of that has to come out as
+    the reference has it, by every search."""
+    from raytracing_amd import scenes
+    spec = importlib.util.spec_from_file_location(
+        "flat_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "flat_probe.py"))
+    flat = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(flat)
+    objs = flat.scene_of("room", 40)
+    sun = (3.0, 2.0, 5.0)
+    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun)
+    monkeypatch.setenv("RAYS_HIP_SHADOW", "walk")
+    g = Scene(ctx, objs)
+    o = oracle.OracleScene(objs)
+    try:
+        ref, ref_ids, _ = o.render(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=sun, want_hit_ids=True)
+        assert (ref_ids != 0xFFFFFFFF).mean() > 0.9
+        monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
+        assert _stats(g, p)["camera_by_projection"] == 1
+        for how in ("1", "atomic", "0"):
+            monkeypatch.setenv("RAYS_HIP_RASTER", how)
+            rgba, ids = g.render(p, want_hit_ids=True)
+            assert np.array_equal(ids, ref_ids), f"RAYS_HIP_RASTER={how}: {int((ids != ref_ids).sum())} hit ids differ"
+            assert np.abs(rgba.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+        rays = scenes.camera_rays(W, H, 2)
+        for how in ("persistent", "wave", "lane"):
+            monkeypatch.setenv("RAYS_HIP_TRACE", how)
+            got = g.trace_closest(rays)["tri"]
+            assert np.array_equal(got, ref_ids), f"{how}: {int((got != ref_ids).sum())} of {len(ref_ids)} hit ids differ"
+    finally:
+        g.close()
+        o.close()
+
+
 @pytest.mark.parametrize("seed", [20094, 5003])
 def test_rays_sent_back_to_the_reference_search(ctx, monkeypatch, seed):
     """A ray whose occluder fails the leaf's box test goes to a second kernel that runs the reference's

@@ -30,44 +30,50 @@ def grid(origin, du, dv, n):
     return t.astype(np.float32)
 
 
-def scene_of(which):
+def scene_of(which, n=None):
     if which == "wall":      # one wall at z = 10 filling the frame
-        return [fuzz.as_object(grid((-20, -12, 10), (40, 0, 0), (0, 24, 0), 200))]
+        return [fuzz.as_object(grid((-20, -12, 10), (40, 0, 0), (0, 24, 0), n or 200))]
     if which == "room":      # back wall, floor, ceiling, two side walls
-        parts = [grid((-8, -4, 16), (16, 0, 0), (0, 8, 0), 96), grid((-8, -4, 2), (16, 0, 0), (0, 0, 14), 96),
-                 grid((-8, 4, 2), (16, 0, 0), (0, 0, 14), 96), grid((-8, -4, 2), (0, 8, 0), (0, 0, 14), 96),
-                 grid((8, -4, 2), (0, 8, 0), (0, 0, 14), 96)]
+        m = n or 96
+        parts = [grid((-8, -4, 16), (16, 0, 0), (0, 8, 0), m), grid((-8, -4, 2), (16, 0, 0), (0, 0, 14), m),
+                 grid((-8, 4, 2), (16, 0, 0), (0, 0, 14), m), grid((-8, -4, 2), (0, 8, 0), (0, 0, 14), m),
+                 grid((8, -4, 2), (0, 8, 0), (0, 0, 14), m)]
         return [fuzz.as_object(np.concatenate(parts))]
     if which == "tilted":    # the same wall turned a little: nothing axis-aligned
-        return [fuzz.as_object(grid((-20, -12, 10), (40, 0, 3), (0, 24, 2), 200))]
+        return [fuzz.as_object(grid((-20, -12, 10), (40, 0, 3), (0, 24, 2), n or 200))]
     raise SystemExit(which)
 
 
-hip = ctypes.CDLL("libamdhip64.so")
-def ev():
-    e = ctypes.c_void_p(); assert hip.hipEventCreate(ctypes.byref(e)) == 0; return e
-def ms(a, b):
-    m = ctypes.c_float(); assert hip.hipEventElapsedTime(ctypes.byref(m), a, b) == 0; return m.value
+def main():
+    hip = ctypes.CDLL("libamdhip64.so")
+    def ev():
+        e = ctypes.c_void_p(); assert hip.hipEventCreate(ctypes.byref(e)) == 0; return e
+    def ms(a, b):
+        m = ctypes.c_float(); assert hip.hipEventElapsedTime(ctypes.byref(m), a, b) == 0; return m.value
 
-label = sys.argv[1] if len(sys.argv) > 1 else ""
-os.environ["RAYS_HIP_RASTER_RATIO"] = "1e9"
-if os.environ.get("FLAT_WALK"):       # the same frames with every ray by tree walk
-    os.environ["RAYS_HIP_RASTER"] = "0"
-    os.environ["RAYS_HIP_SHADOW"] = "walk"
-ctx = Context(0)
-for which in ("wall", "tilted", "room"):
-    scene = Scene(ctx, scene_of(which))
-    p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=(3.0, 2.0, 5.0))
-    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
-    st = scene.render_device_stats(p, frame.data_ptr())
-    sh = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
-        scene.render_device(p, frame.data_ptr(), None, sh)
-    evs = [[ev() for _ in range(8)] for _ in range(6)]
-    for e in evs:
-        scene.render_device_events(p, frame.data_ptr(), [x.value for x in e], None, sh)
-    torch.cuda.synchronize()
-    ph = [np.mean([ms(e[k], e[k + 1]) for e in evs]) for k in range(4)]
-    print(f"{label:12s} {which:7s} by projection {st['camera_by_projection']}  by cells {st['shadow_by_cells']}  total {sum(ph):6.2f} ms  cam {ph[0]:6.2f} sort {ph[1]:5.2f} shd {ph[2]:5.2f} res {ph[3]:5.2f}", flush=True)
-    scene.close()
-ctx.close()
+    label = sys.argv[1] if len(sys.argv) > 1 else ""
+    os.environ["RAYS_HIP_RASTER_RATIO"] = "1e9"
+    if os.environ.get("FLAT_WALK"):       # the same frames with every ray by tree walk
+        os.environ["RAYS_HIP_RASTER"] = "0"
+        os.environ["RAYS_HIP_SHADOW"] = "walk"
+    ctx = Context(0)
+    for which in ("wall", "tilted", "room"):
+        scene = Scene(ctx, scene_of(which))
+        p = render_params(W, H, 2, reflect_depth=1, diffuse_depth=1, sun=(3.0, 2.0, 5.0))
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        st = scene.render_device_stats(p, frame.data_ptr())
+        sh = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            scene.render_device(p, frame.data_ptr(), None, sh)
+        evs = [[ev() for _ in range(8)] for _ in range(6)]
+        for e in evs:
+            scene.render_device_events(p, frame.data_ptr(), [x.value for x in e], None, sh)
+        torch.cuda.synchronize()
+        ph = [np.mean([ms(e[k], e[k + 1]) for e in evs]) for k in range(4)]
+        print(f"{label:12s} {which:7s} by projection {st['camera_by_projection']}  by cells {st['shadow_by_cells']}  total {sum(ph):6.2f} ms  cam {ph[0]:6.2f} sort {ph[1]:5.2f} shd {ph[2]:5.2f} res {ph[3]:5.2f}", flush=True)
+        scene.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
