@@ -3176,7 +3176,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* __restrict__ coun
 #define RT_SEG 4u    // rows of a triangle's box that one lane goes down
 #endif
 #ifndef RT_RUN
-#define RT_RUN 16u  // longest run of samples queued as one entry (a longer span of a row is queued in pieces)
+#define RT_RUN 8u   // longest run of samples queued as one entry (a longer span of a row is queued in pieces; 16 is
+                    // 0.02 ms faster by itself and costs the LDS that an eleventh group per CU needs: 0.05 ms)
 #endif
 struct RasterTileLds {
     unsigned long long z[RT_RTILE * RT_RTILE];   // nearest (t, id) per sample of the tile, row by row
@@ -3185,7 +3186,11 @@ struct RasterTileLds {
     uint16_t samples[RT_RTILE_GROUP][64 * RT_RUN];   // per wave: the samples of up to 64 runs, packed: sample | slot << 10
     uint16_t segs[RT_RTILE_GROUP][64 * (RT_RTILE / RT_SEG)];   // per wave: row segments of the current 64 triangles: lane | segment << 6
     float dx[RT_RTILE], dy[RT_RTILE];            // image-plane coordinates of the tile's columns and rows
-    float idx[RT_RTILE], idy[RT_RTILE];          // their reciprocals, as Ray.inv_dir holds them (src/main.rs:329)
+    // (Their reciprocals, as Ray.inv_dir holds them (src/main.rs:329), are wanted by the record loop only: they
+    // go where the sample codes were, see recip_x. With that and runs of eight the structure is 14,080 bytes,
+    // eleven of the 1,280-byte pieces LDS is handed out in, and a CU holds eleven groups instead of ten.)
+    __device__ __forceinline__ float* recip_x() { return reinterpret_cast<float*>(&samples[0][0]); }
+    __device__ __forceinline__ float* recip_y() { return recip_x() + RT_RTILE; }
     // Tie bits, one per sample: two accepted triangles within RT_TIE_ULPS of each other in t. They live in
     // the twelfth word of the triangle slots (an array of their own took the structure past a multiple
     // of the 1,280 bytes LDS is handed out in, and the kernel from ten groups a CU to nine: 0.07 ms a frame).
@@ -3311,10 +3316,10 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     for (uint32_t i = threadIdx.x; i < RT_RTILE * RT_RTILE / 32u; i += 64u * RT_RTILE_GROUP) *lds.tie_word(i) = 0u;
     if (threadIdx.x < RT_RTILE) {
         const float c = tab[min(su0 + (int)threadIdx.x, gw - 1)];
-        lds.dx[threadIdx.x] = c, lds.idx[threadIdx.x] = 1.0f / c;
+        lds.dx[threadIdx.x] = c;
     } else if (threadIdx.x < 2u * RT_RTILE) {
         const float c = tab[gw + min(sw0 + (int)(threadIdx.x - RT_RTILE), gh - 1)];
-        lds.dy[threadIdx.x - RT_RTILE] = c, lds.idy[threadIdx.x - RT_RTILE] = 1.0f / c;
+        lds.dy[threadIdx.x - RT_RTILE] = c;
     }
     __syncthreads();
 
@@ -3507,6 +3512,10 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     }
 
     __syncthreads();   // both waves' nearest hits are in
+    static_assert(sizeof(lds.samples) >= 2 * RT_RTILE * sizeof(float), "the reciprocals take the sample codes' place");
+    if (threadIdx.x < RT_RTILE) lds.recip_x()[threadIdx.x] = 1.0f / lds.dx[threadIdx.x];
+    else if (threadIdx.x < 2u * RT_RTILE) lds.recip_y()[threadIdx.x - RT_RTILE] = 1.0f / lds.dy[threadIdx.x - RT_RTILE];
+    __syncthreads();
 #ifdef RT_DEBUG_RASTER
     if (dbg_tile && lane == 0) printf("tile final z[%u] = %llx\n", dbg_zi, lds.z[dbg_zi]);
 #endif
@@ -3529,7 +3538,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
     // tile's samples, in no particular order, so the next id is looked for anew each time: a few thousand
     // triangle tests for one sample in many millions.
     auto rescan = [&](uint32_t sl, uint32_t wl) -> unsigned long long {
-        const rt_f3 d = f3(lds.dx[sl], lds.dy[wl], 1.0f), inv = f3(lds.idx[sl], lds.idy[wl], 1.0f);
+        const rt_f3 d = f3(lds.dx[sl], lds.dy[wl], 1.0f), inv = f3(lds.recip_x()[sl], lds.recip_y()[wl], 1.0f);
         unsigned long long best = RT_ZKEY_NONE;
         float closest = RT_INF, packet_closest = RT_INF;
         uint32_t last = 0, packet = 0xFFFFFFFFu, packet_obj = 0xFFFFFFFFu;
@@ -3604,7 +3613,7 @@ __global__ __launch_bounds__(64 * RT_RTILE_GROUP, RT_RTILE_WAVES) void k_raster_
         // trailing triangles come last, see rt_scene_build.)
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
-            const rt_f3 inv = f3(lds.idx[sul[u]], lds.idy[swl[u]], 1.0f);
+            const rt_f3 inv = f3(lds.recip_x()[sul[u]], lds.recip_y()[swl[u]], 1.0f);
             if (hit_any[u] && !ref_leaf_gate(leaf_lo[u], leaf_hi[u], o, inv, hs[u].t)) {
                 // A hit in the very plane of its leaf's box (an axis-aligned wall) fails this by rounding as
                 // often as not. The order matters only if another accepted triangle lies between the hit
