@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 // the first occluder and hit.tri != RT_MISS says "occluded".
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_WALK_LDS
-#define RT_WALK_LDS 12
+#define RT_WALK_LDS 13
 #endif
 #ifndef RT_REFILL
 #define RT_REFILL 16
@@ -1499,13 +1499,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_LANE_WAVES) void k_trace_closest(Scene
 #define RT_WALK_HEADROOM (RT_WALK_MAX_GRID * RT_CHUNK + 64u)  // counter overshoot at the end of a launch
 // Stack of the persistent walk: RT_WALK_LDS entries of 6 bytes in LDS (node reference, and the
 // entry distance cut to its upper 16 bits: rounded towards zero, so an entry is never dropped that
-// the full distance would keep), the rest in private memory. 12 entries per lane of 32 waves are
-// 147 KB of the CU's 160 KB; with 8-byte entries the same LDS held 8, and every entry more that
-// stays out of private memory is worth about 3 % on incoherent rays.
+// the full distance would keep), the rest in private memory. LDS is handed out in pieces of 1,280
+// bytes and 32 waves a CU can have four each: 13 entries per lane are 4,992 bytes a wave, and nothing else of
+// a walk kernel's may live in LDS. With 8-byte entries the same LDS held 8; every entry more that stays out
+// of private memory is worth 2 to 3 % on incoherent rays.
 struct WalkLds {
     uint32_t refs[RT_WALK_LDS * 64];
     uint16_t keys[RT_WALK_LDS * 64];
 };
+static_assert(sizeof(WalkLds) <= 4 * 1280, "a walk's LDS has to leave room for 32 waves a CU");
 struct WalkStack {
     WalkLds* lds;    // the wave's block (wave-uniform); entry e of this lane at [e * 64 + threadIdx.x]
     uint2* spill;    // RT_STACK_MAX - RT_WALK_LDS entries of the caller's, in private memory. (An array inside
@@ -4379,9 +4381,8 @@ __device__ __forceinline__ rt_f3 reflect_dir(rt_f3 d, rt_f3 n) { return d - 2.0f
 // hit a mirror. Directions are not stored: they follow from the stored triangle ids along the branch.
 // Records of rays that do not exist: level 0 stores "no hit, no shadow ray" itself, the deeper
 // levels are preset to that before the first launch.
-#define RT_QUEUE_LDS 96   // follow-up rays a wave collects: written out from 32 on, and a turn adds at most 64
 struct TreeSource {
-    static constexpr bool QUEUES = true;
+    static constexpr bool QUEUES = false;   // follow-up rays go straight to the next level's queue (emit)
     const SceneView& sv;
     const DevRenderParams& p;
     const LightProj& lp;
@@ -4396,7 +4397,6 @@ struct TreeSource {
     const uint32_t* queue;  // this level's rays (level > 0)
     uint32_t* next_queue;   // the next level's rays and their count, null at the last level
     uint32_t* next_count;
-    uint32_t* s_q;          // LDS, per wave: RT_QUEUE_LDS entries, then their count
     __device__ __forceinline__ bool none(uint32_t j) const {
         dstate[j] = 0u;
         dkeys[j] = 0xFFFFFFFFu;
@@ -4449,34 +4449,21 @@ struct TreeSource {
             dkeys[i] = lit ? light_key(lp, s2.pos) : 0xFFFFFFFFu;
             spawn = next_queue != nullptr && s2.reflectivity > 0.0f;
         }
-        // The lanes that emit in this turn and bounce on append to the wave's list together. The list's
-        // length is written by one lane and read by all in the next turn: the hardware serves a wave's
-        // LDS instructions in order, the fences keep the compiler from moving or caching them.
+        // The lanes that emit in this turn and bounce on append to the next level's queue together: one
+        // atomic for all of them. (A list per wave in LDS, written out 32 rays at a time, saved atomics that
+        // are few anyway -- one turn in many has a mirror hit -- and its 388 bytes kept the walk's stack in
+        // LDS one entry shorter: LDS is handed out in pieces of 1,280 bytes, 32 waves a CU get four each.)
         const unsigned long long mask = __ballot(spawn);
-        wave_lds_sync();
         if (spawn) {
             const uint32_t lane = threadIdx.x & 63u;
-            const uint32_t base = s_q[RT_QUEUE_LDS];
-            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            s_q[base + rank] = j;
-            if (rank == 0) s_q[RT_QUEUE_LDS] = base + (uint32_t)__builtin_popcountll(mask);
+            const int first = __builtin_ctzll(mask);
+            uint32_t base = 0;
+            if ((int)lane == first) base = atomicAdd(next_count, (uint32_t)__builtin_popcountll(mask));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+            next_queue[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = j;
         }
-        wave_lds_sync();
     }
-    // Whole wave: writes the collected rays out once there are 32 (or any, at the end), one atomic
-    // per write. A turn adds at most 64, so the list never passes 95.
-    __device__ __forceinline__ void flush(uint32_t lane, bool all) const {
-        if (!next_queue) return;
-        const uint32_t n = s_q[RT_QUEUE_LDS];
-        if (n == 0 || (!all && n < 32u)) return;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(next_count, n);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        for (uint32_t i = lane; i < n; i += 64u) next_queue[base + i] = s_q[i];
-        wave_lds_sync();
-        if (lane == 0) s_q[RT_QUEUE_LDS] = 0u;
-        wave_lds_sync();
-    }
+    __device__ __forceinline__ void flush(uint32_t, bool) const {}
 };
 
 // counts: one word per level, the number of rays in that level's queue (level 0 has none: it runs
@@ -4490,15 +4477,13 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
                                                     uint32_t* queues, uint32_t* counts,
                                                     DevStats* __restrict__ stats) {
     __shared__ WalkLds s_stack;
-    __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
-    if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
     LaneStats st;
     const bool last = level + 1 >= tr.levels;
     const uint32_t n = level ? counts[level] : tr.level_rays;
     const TreeSource src{sv, p, lp, tr, level, tile_list, samp, state, dsamp, dstate, dkeys,
                          queues + (size_t)level * tr.level_rays,
                          last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
-                         last ? nullptr : counts + level + 1, s_q};
+                         last ? nullptr : counts + level + 1};
 #ifdef RT_DEBUG_CLOCK
     const long long c0 = clock64(), w0 = wall_clock64();
 #endif
@@ -4516,14 +4501,12 @@ __global__ __launch_bounds__(64) void k_wf_bounce_redo(SceneView sv, DevRenderPa
                                                        const float4* __restrict__ samp, const uint32_t* __restrict__ state,
                                                        float4* dsamp, uint32_t* dstate, uint32_t* __restrict__ dkeys,
                                                        uint32_t* queues, uint32_t* counts) {
-    __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
-    if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
     const bool last = level + 1 >= tr.levels;
     const uint32_t n = level ? counts[level] : tr.level_rays;
     const TreeSource src{sv, p, lp, tr, level, tile_list, samp, state, dsamp, dstate, dkeys,
                          queues + (size_t)level * tr.level_rays,
                          last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
-                         last ? nullptr : counts + level + 1, s_q};
+                         last ? nullptr : counts + level + 1};
     redo_marked(sv, n, src);
 }
 
