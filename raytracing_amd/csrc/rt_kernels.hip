@@ -4381,8 +4381,12 @@ __device__ __forceinline__ rt_f3 reflect_dir(rt_f3 d, rt_f3 n) { return d - 2.0f
 // hit a mirror. Directions are not stored: they follow from the stored triangle ids along the branch.
 // Records of rays that do not exist: level 0 stores "no hit, no shadow ray" itself, the deeper
 // levels are preset to that before the first launch.
+// Follow-up rays a wave collects in LDS before it writes them to the next level's queue with one atomic (an
+// atomic per finishing turn on the one counter all waves share doubled the time of a frame full of mirrors).
+// With its count the list is 128 bytes: what thirteen stack entries per lane leave of a walk's 5,120.
+#define RT_QUEUE_LDS 31
 struct TreeSource {
-    static constexpr bool QUEUES = false;   // follow-up rays go straight to the next level's queue (emit)
+    static constexpr bool QUEUES = true;
     const SceneView& sv;
     const DevRenderParams& p;
     const LightProj& lp;
@@ -4397,6 +4401,7 @@ struct TreeSource {
     const uint32_t* queue;  // this level's rays (level > 0)
     uint32_t* next_queue;   // the next level's rays and their count, null at the last level
     uint32_t* next_count;
+    uint32_t* s_q;          // LDS, per wave: RT_QUEUE_LDS entries, then their count
     __device__ __forceinline__ bool none(uint32_t j) const {
         dstate[j] = 0u;
         dkeys[j] = 0xFFFFFFFFu;
@@ -4449,21 +4454,56 @@ struct TreeSource {
             dkeys[i] = lit ? light_key(lp, s2.pos) : 0xFFFFFFFFu;
             spawn = next_queue != nullptr && s2.reflectivity > 0.0f;
         }
-        // The lanes that emit in this turn and bounce on append to the next level's queue together: one
-        // atomic for all of them. (A list per wave in LDS, written out 32 rays at a time, saved atomics that
-        // are few anyway -- one turn in many has a mirror hit -- and its 388 bytes kept the walk's stack in
-        // LDS one entry shorter: LDS is handed out in pieces of 1,280 bytes, 32 waves a CU get four each.)
+        // The lanes that emit in this turn and bounce on append to the wave's list together; a list that
+        // cannot take them is written out first, by the lanes that are here (emit runs for the lanes that
+        // finish in a turn, not for the wave), and more than the list holds go out by themselves. The
+        // hardware serves a wave's LDS instructions in order; the fences keep the compiler from moving or
+        // caching them.
         const unsigned long long mask = __ballot(spawn);
-        if (spawn) {
+        if (mask != 0ull) {
             const uint32_t lane = threadIdx.x & 63u;
-            const int first = __builtin_ctzll(mask);
-            uint32_t base = 0;
-            if ((int)lane == first) base = atomicAdd(next_count, (uint32_t)__builtin_popcountll(mask));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-            next_queue[base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = j;
+            const unsigned long long here = __ballot(true);
+            const int first = __builtin_ctzll(here);
+            const uint32_t add = (uint32_t)__builtin_popcountll(mask);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            wave_lds_sync();
+            uint32_t n = s_q[RT_QUEUE_LDS];
+            if (add > RT_QUEUE_LDS) {
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(next_count, add);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                if (spawn) next_queue[base + rank] = j;
+            } else {
+                if (n + add > RT_QUEUE_LDS) {
+                    const uint32_t me = (uint32_t)__builtin_popcountll(here & ((1ull << lane) - 1ull));
+                    const uint32_t lanes = (uint32_t)__builtin_popcountll(here);
+                    uint32_t base = 0;
+                    if ((int)lane == first) base = atomicAdd(next_count, n);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                    for (uint32_t i = me; i < n; i += lanes) next_queue[base + i] = s_q[i];
+                    wave_lds_sync();
+                    n = 0;
+                }
+                if (spawn) s_q[n + rank] = j;
+                if ((int)lane == first) s_q[RT_QUEUE_LDS] = n + add;
+                wave_lds_sync();
+            }
         }
     }
-    __device__ __forceinline__ void flush(uint32_t, bool) const {}
+    // Whole wave, at the end of the walk: writes out what is left in the list.
+    __device__ __forceinline__ void flush(uint32_t lane, bool all) const {
+        if (!all || !next_queue) return;
+        wave_lds_sync();
+        const uint32_t n = s_q[RT_QUEUE_LDS];
+        if (n == 0) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_count, n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < n; i += 64u) next_queue[base + i] = s_q[i];
+        wave_lds_sync();
+        if (lane == 0) s_q[RT_QUEUE_LDS] = 0u;
+        wave_lds_sync();
+    }
 };
 
 // counts: one word per level, the number of rays in that level's queue (level 0 has none: it runs
@@ -4477,13 +4517,16 @@ __global__ __launch_bounds__(64, RT_WALK_WAVES) void k_wf_bounce(SceneView sv, D
                                                     uint32_t* queues, uint32_t* counts,
                                                     DevStats* __restrict__ stats) {
     __shared__ WalkLds s_stack;
+    __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
+    static_assert(sizeof(WalkLds) + sizeof(s_q) <= 4 * 1280, "a walk's LDS has to leave room for 32 waves a CU");
+    if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
     LaneStats st;
     const bool last = level + 1 >= tr.levels;
     const uint32_t n = level ? counts[level] : tr.level_rays;
     const TreeSource src{sv, p, lp, tr, level, tile_list, samp, state, dsamp, dstate, dkeys,
                          queues + (size_t)level * tr.level_rays,
                          last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
-                         last ? nullptr : counts + level + 1};
+                         last ? nullptr : counts + level + 1, s_q};
 #ifdef RT_DEBUG_CLOCK
     const long long c0 = clock64(), w0 = wall_clock64();
 #endif
@@ -4501,12 +4544,14 @@ __global__ __launch_bounds__(64) void k_wf_bounce_redo(SceneView sv, DevRenderPa
                                                        const float4* __restrict__ samp, const uint32_t* __restrict__ state,
                                                        float4* dsamp, uint32_t* dstate, uint32_t* __restrict__ dkeys,
                                                        uint32_t* queues, uint32_t* counts) {
+    __shared__ uint32_t s_q[RT_QUEUE_LDS + 1];
+    if (threadIdx.x == 0) s_q[RT_QUEUE_LDS] = 0u;
     const bool last = level + 1 >= tr.levels;
     const uint32_t n = level ? counts[level] : tr.level_rays;
     const TreeSource src{sv, p, lp, tr, level, tile_list, samp, state, dsamp, dstate, dkeys,
                          queues + (size_t)level * tr.level_rays,
                          last ? nullptr : queues + (size_t)(level + 1) * tr.level_rays,
-                         last ? nullptr : counts + level + 1};
+                         last ? nullptr : counts + level + 1, s_q};
     redo_marked(sv, n, src);
 }
 
