@@ -2,7 +2,6 @@
 // nodes laid out in depth-first order. Host code; runs once per scene.
 
 #include "bvh_build.h"
-#include "rt_device.h"
 
 #include <algorithm>
 #include <atomic>
@@ -27,7 +26,7 @@ constexpr float PAD_REL = 6e-6f;
 // PAD_ABS is ten times what those roundings need: the nearest-hit walks rely on reaching every triangle
 // whose hit lies less than half the padding (as a distance along the ray) behind the nearest one (tie_note
 // in rt_kernels.hip, which reads the same constant).
-constexpr float PAD_ABS = RT_PAD_ABS;   // rt_device.h
+constexpr float PAD_ABS = RT_PAD_ABS;   // bvh_build.h
 
 // Tuning knobs (environment, read once): largest leaf and the price of one traversal step in
 // triangle tests.

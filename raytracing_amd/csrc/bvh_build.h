@@ -1,13 +1,19 @@
 // bvh_build.h -- host-side builder of the 4-wide bounding volume hierarchy the traversal kernels
 // walk. The reference has no tree (it scans every 8-triangle leaf box of an object in turn,
 // src/main.rs:103); the tree only has to be conservative with respect to the reference's
-// per-triangle arithmetic, because the nearest hit does not depend on the visiting order.
+// per-triangle arithmetic, because the nearest hit does not depend on the visiting order (but for the
+// reference's rule about triangles within rounding of each other, which the searches settle themselves:
+// closest_resolve in rt_kernels.hip).
 #ifndef RT_BVH_BUILD_H
 #define RT_BVH_BUILD_H
 
 #include <stdint.h>
 
 #include <vector>
+
+// Absolute part of the padding of the trees' boxes, as a fraction of the object's largest coordinate (the
+// builders' PAD_ABS; the nearest-hit walks' tie notes count on it).
+#define RT_PAD_ABS 1e-5f
 
 namespace rtbvh {
 

@@ -16,9 +16,6 @@
 #define RT_STACK_SPILL 80   // further entries in private memory
 #endif
 #define RT_STACK_MAX (RT_STACK_LDS + RT_STACK_SPILL)
-// Absolute part of the padding of the trees' boxes, as a fraction of the object's largest coordinate (the
-// builders' PAD_ABS; the nearest-hit walks' tie notes count on it).
-#define RT_PAD_ABS 1e-5f
 #define RT_MAX_REFLECT 8    // deepest mirror chain the frame kernel keeps on its stack
 #define RT_BEAM_LEVELS 16   // wide-tree levels whose pending children a wave keeps in LDS
 

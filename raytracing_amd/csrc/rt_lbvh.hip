@@ -34,7 +34,7 @@ constexpr float PAD_REL = 6e-6f;
 // PAD_ABS is ten times what those roundings need: the nearest-hit walks rely on reaching every triangle
 // whose hit lies less than half the padding (as a distance along the ray) behind the nearest one (tie_note
 // in rt_kernels.hip, which reads the same constant).
-constexpr float PAD_ABS = RT_PAD_ABS;   // rt_device.h
+constexpr float PAD_ABS = RT_PAD_ABS;   // bvh_build.h
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {
     v &= 0x3FFu;
