@@ -34,7 +34,8 @@ struct HitD {
     uint32_t obj;
     float t, u, v;
     float closest;
-    bool tie;   // the current object's walk has met two accepted triangles within RT_TIE_WALK ulps of each other (tie_note)
+    uint32_t near;   // the current object's walk: least distance, in units of the last place, between an accepted
+                     // triangle's t and the nearest distance of that moment (tie_note); a tie when <= RT_TIE_WALK
 };
 // Walks note when an accepted triangle's t lies within RT_TIE_WALK units of the last place of the nearest
 // distance of that moment, on either side (+inf, the distance before any hit, is near nothing). The nearest
@@ -44,10 +45,13 @@ struct HitD {
 // than pad / |d| behind the nearest one is never culled: its box begins that much before its hit along
 // whichever axis it is entered by. closest_needs_resolve relies on half of that.
 #define RT_TIE_WALK 1024u
-__device__ __forceinline__ void tie_note(float t, float closest, bool accepted, bool& tie) {
+// (The note is a minimum kept in a vector register: a flag per lane that changes inside the walks' loops is kept
+// as a mask in scalar registers and merged at every join of the control flow, which cost the camera rays' walk
+// 0.2 ms of 3.1.)
+__device__ __forceinline__ void tie_note(float t, float closest, bool accepted, uint32_t& near) {
     uint32_t apart;
     asm("v_sad_u32 %0, %1, %2, 0" : "=v"(apart) : "v"(__float_as_uint(t)), "v"(__float_as_uint(closest)));
-    tie = tie || (accepted && apart <= RT_TIE_WALK);
+    near = min(near, accepted ? apart : 0xFFFFFFFFu);
 }
 
 __device__ __forceinline__ rt_f3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
@@ -250,7 +254,7 @@ __device__ __forceinline__ bool record_test(float4 ra, float4 rb, float4 rc, uin
     const uint32_t id = __float_as_uint(rc.y);
     const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
     if (ANY) return !ev.failed && !__builtin_signbit(ev.t) && !(ev.t != ev.t);
-    tie_note(ev.t, closest, !ev.failed && ev.t > 0.0f, hit.tie);
+    tie_note(ev.t, closest, !ev.failed && ev.t > 0.0f, hit.near);
     const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
     if (!ev.failed && ev.t > 0.0f && better) {
         closest = ev.t;
@@ -284,7 +288,7 @@ __device__ __forceinline__ bool bvh_search(const SceneView& sv, uint32_t root, u
                                            LaneStats& st) {
     const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
     uint32_t local_best = 0;
-    hit.tie = false;
+    hit.near = 0xFFFFFFFFu;
     stk.sp = 0;
     uint32_t cur = root;
     for (;;) {
@@ -335,7 +339,7 @@ __device__ __forceinline__ bool closest_needs_resolve(const SceneView& sv, uint3
     const float4* lg = sv.leaf_gate + 2 * (size_t)(leaf_base + ((hit.tri - tri_base) >> 3));
     const float4 lo4 = lg[0], hi4 = lg[1];
     if (ref_leaf_gate(lo4, hi4, o, inv, hit.t)) return false;
-    if (hit.tie) return true;
+    if (hit.near <= RT_TIE_WALK) return true;
     const DevObject& ob = sv.objs[oi];
     // how far behind the hit the walk is sure to have tested everything: half the boxes' padding, as a distance
     // along the ray, and no farther than the ties are noted
@@ -507,7 +511,7 @@ __device__ __noinline__ bool gated_nearest(const SceneView& sv, uint32_t oi, flo
     uint32_t cur = ob.root;
     const rt_f3 o = r.o, d = r.d, inv = g_recip(d);
     float closest = before;
-    bool tie = false;
+    uint32_t near = 0xFFFFFFFFu;
     for (;;) {
         if (!(cur & LEAF_BIT)) {
             const float4* np = reinterpret_cast<const float4*>(sv.nodes + cur);
@@ -535,7 +539,7 @@ __device__ __noinline__ bool gated_nearest(const SceneView& sv, uint32_t oi, flo
                 const uint32_t id = __float_as_uint(rc.y);
                 const float4* lg = resolve_gate_of(sv, ob, id);
                 if (!ref_leaf_gate(lg[0], lg[1], o, inv)) continue;
-                tie_note(ev.t, closest, true, tie);
+                tie_note(ev.t, closest, true, near);
                 if (ev.t < closest || (ev.t == closest && best != RT_MISS && id < best)) {
                     closest = ev.t, best = id;
                     r.hit.tri = id, r.hit.obj = oi, r.hit.t = ev.t, r.hit.u = ev.u, r.hit.v = ev.v;
@@ -545,7 +549,7 @@ __device__ __noinline__ bool gated_nearest(const SceneView& sv, uint32_t oi, flo
         if (sp == 0) break;
         cur = stack[--sp];
     }
-    r.hit.tie = tie;
+    r.hit.near = near;
     r.closest = closest;
     if (best == RT_MISS) r.hit.tri = RT_MISS;
     return true;
@@ -772,8 +776,7 @@ __device__ __forceinline__ void packet_tri(const f32x8_t ra, const f32x4_t rb, u
         } else {
             const rt_tri_eval ev = tri_intersect(e1, e2, v0, o, d);
             const bool accepted = pred && !ev.failed && ev.t > 0.0f;
-            // (most triangles a wave fetches are accepted by none of its rays: one scalar branch skips the note)
-            if (__ballot(accepted) != 0ull) tie_note(ev.t, closest, accepted, hit.tie);
+            tie_note(ev.t, closest, accepted, hit.near);
             const bool better = (ev.t < closest) || (ev.t == closest && id < local_best);
             if (accepted && better) {
                 closest = ev.t;
@@ -848,7 +851,7 @@ __device__ __forceinline__ void packet_search(const SceneView& sv, uint32_t root
     const int lane = (int)(threadIdx.x & 63u);
     const float nox = -(o.x * inv.x), noy = -(o.y * inv.y), noz = -(o.z * inv.z);
     uint32_t local_best = 0;
-    hit.tie = false;
+    hit.near = 0xFFFFFFFFu;
     WaveStack stk;
     uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)root);
     for (;;) {
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ bool beam_search(const SceneView& sv, uint32_t root_r
     const uint32_t lane = threadIdx.x & 63u;
     if (STATS && lane == 0) st.walks[0] += 1;
     uint32_t local_best = 0;
-    hit.tie = false;
+    hit.near = 0xFFFFFFFFu;
     // Farthest useful w per lane, relative to wbase: where the ray's current nearest hit lies.
     auto far_rel = [&](float c) {
         const float z = __builtin_fmaf(c, bl.dw, bl.ow);
@@ -1679,7 +1682,7 @@ __device__ __forceinline__ void persistent_walk(const SceneView& sv, uint32_t n_
                     walking = true;
                     cur = root;
                     local_best = 0;
-                    hit.tie = false;
+                    hit.near = 0xFFFFFFFFu;
                     stk.reset();
                 }
             } else {
@@ -3714,7 +3717,7 @@ __global__ __launch_bounds__(BLOCK) void k_raster_records(SceneView sv, DevRende
     state[slot] = (hit_any ? RT_ST_HIT : 0u) | (lit ? RT_ST_LIT : 0u) | (hs.obj << 8);
     keys[slot] = lit ? light_key(lp, sf.pos) : 0xFFFFFFFFu;
     // a nearest hit whose place in the reference's order could matter is left to k_wf_primary_redo
-    hs.tie = true;   // (nothing is known of the other triangles at this sample)
+    hs.near = 0u;   // (nothing is known of the other triangles at this sample)
     if (hit_any && closest_needs_resolve(sv, hs.obj, o, d, g_recip(d), hs)) state[slot] = RT_ST_REDO, keys[slot] = 0xFFFFFFFFu;
     if (STATS) {
         LaneStats st;
