@@ -175,6 +175,37 @@ def test_coplanar_layers_follow_the_order_of_the_reference_search(ctx, oracle, m
         o.close()
 
 
+@pytest.mark.parametrize("depths", [(3, 1), (2, 2)])
+def test_order_rule_reaches_mirror_and_scatter_rays(ctx, oracle, monkeypatch, depths):
+    """Seed 60000 again (coplanar layers whose triangles face either way), now shiny: mirror frames go
+    through the frame kernel's own searches, frames with scatter rays through the persistent walk and the
+    kernel behind it, and a secondary ray that picks the wrong one of two coplanar triangles leaves with
+    the wrong normal. Frames against the oracle's, every path."""
+    from raytracing_amd import _ffi
+    fuzz = _fuzz(monkeypatch)
+    objs, sun = _scene(fuzz, 60000)
+    for ob in objs:
+        ob["material"] = _ffi.material(1.0, 0.5, 1.0)
+    w, h = 320, 180
+    reflect, diffuse = depths
+    p = render_params(w, h, 2, reflect_depth=reflect, diffuse_depth=diffuse, diffuse_scatt=4, sun=sun, seed=7)
+    g = Scene(ctx, objs)
+    o = oracle.OracleScene(objs)
+    try:
+        ref, ref_ids, _ = o.render(w, h, 2, reflect_depth=reflect, diffuse_depth=diffuse, diffuse_scatt=4, sun=sun, seed=7,
+                                   want_hit_ids=True)
+        for raster in ("1", "0"):
+            monkeypatch.setenv("RAYS_HIP_RASTER", raster)
+            monkeypatch.setenv("RAYS_HIP_RASTER_RATIO", "1e9")
+            rgba, ids = g.render(p, want_hit_ids=True)
+            assert np.array_equal(ids, ref_ids), f"RAYS_HIP_RASTER={raster}: {int((ids != ref_ids).sum())} hit ids differ"
+            off = np.abs(rgba.astype(np.int16) - ref.astype(np.int16)).max(axis=2) > 1
+            assert not off.any(), f"RAYS_HIP_RASTER={raster}: {int(off.sum())} pixels differ by more than 1 LSB"
+    finally:
+        g.close()
+        o.close()
+
+
 def test_axis_aligned_room_every_search_equals_the_oracle(ctx, oracle, monkeypatch):
     """Five tessellated axis-aligned walls (tools/flat_probe.py): every hit lies in the very plane of its
     leaf's box, a fifth of them fail the box test with the ray cut at the hit by an ulp or two, and rays
